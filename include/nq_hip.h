@@ -1,0 +1,152 @@
+/* nq_hip.h -- C ABI of libnqhip.so: the MI355X (gfx950) kernels behind NeuroQuant's network-wise
+ * calibration hot path.
+ *
+ * The reference (Eric-qi/NeuroQuant) has no FFI layer: its boundary is the Python object API of
+ * quantization/{quantizer,quant_layer,quant_model,calib_model}.py and models/{HNeRV,NeRV}.py.  The Python
+ * host in neuroquant_amd/ keeps that API and reaches every entry point below through ctypes on
+ * torch.cuda.current_stream().  Each entry point names the reference code (file:line under
+ * /root/reference) whose arithmetic it replaces.
+ *
+ * Conventions (all entry points):
+ *   - plain C: device pointers + sizes, no torch types; fp32 tensors, contiguous, NCHW / OIHW;
+ *   - no allocation, no ownership transfer, no host synchronisation: the caller passes outputs and
+ *     workspaces; work is enqueued on `stream` (a hipStream_t) and the call returns immediately;
+ *   - returns NQ_OK (0) or a negative NQ_ERR_* code; nothing throws across the boundary;
+ *   - stateless and re-entrant; pointers must be 16-byte aligned unless stated otherwise.
+ *
+ * "rows x row_len" tensors: a weight (C_out, C_in, k, k) is rows=C_out, row_len=C_in*k*k; a bias is
+ * rows=1, row_len=C_out.  per_row=1 -> delta/zp hold one value per row (channel-wise weight),
+ * per_row=0 -> one scalar for the whole tensor (bias, layer-wise weight)  (quantizer.py:129-153).
+ */
+#ifndef NQ_HIP_H
+#define NQ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nq_stream_t; /* hipStream_t */
+
+#define NQ_OK 0
+#define NQ_ERR_INVALID (-1)     /* bad argument (null pointer, non power-of-two length, size <= 0 ...) */
+#define NQ_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are built for */
+#define NQ_ERR_LAUNCH (-3)      /* HIP reported a launch error */
+
+int nq_abi_version(void);
+const char* nq_error_string(int code);
+
+/* ---------------------------------------------------------------- quantiser parameter side ---- */
+
+/* UniformAffineQuantizer.init_quantization_scale, 'max' branch (quantizer.py:127-168): per row
+ * delta = max((max(x,0)-min(x,0))/(n_levels-1), 1e-8) (division in double, stored fp32),
+ * zp = rint(-min/delta).  One value per row is written; a bias / layer-wise tensor is rows=1. */
+int nq_scale_init_max(const float* x, int64_t rows, int64_t row_len, int n_levels, float* delta, float* zp,
+                      nq_stream_t stream);
+
+/* UniformAffineQuantizer.forward (quantizer.py:117-119): y = (clamp(rint(x/delta)+zp, 0, L-1) - zp)*delta. */
+int nq_uaq_forward(const float* x, const float* delta, const float* zp, float* y, int64_t rows, int64_t row_len,
+                   int per_row, int n_levels, nq_stream_t stream);
+
+/* Backward of the above w.r.t. delta (round_ste, quantizer.py:53-57): ddelta[row] = sum gy*((xq-zp) -
+ * 1{0<=rint(x/delta)+zp<=L-1} * x/delta).  ddelta is overwritten (rows values, or 1 if !per_row). */
+int nq_uaq_backward(const float* x, const float* gy, const float* delta, const float* zp, float* ddelta,
+                    int64_t rows, int64_t row_len, int per_row, int n_levels, nq_stream_t stream);
+
+/* AdaRoundQuantizer.__init__/init_alpha (quantizer.py:264-265, 305-314): delta/zp through an fp16 round
+ * trip, alpha = -log((zeta-gamma)/(frac(x/delta)-gamma) - 1).  delta_out/zp_out have the size of delta_in. */
+int nq_adaround_init(const float* x, const float* delta_in, const float* zp_in, float* delta_out, float* zp_out,
+                     float* alpha, int64_t rows, int64_t row_len, int per_row, nq_stream_t stream);
+
+/* AdaRoundQuantizer.forward 'learned_hard_sigmoid' (quantizer.py:288-300): soft!=0 -> floor(x/delta)+h(alpha),
+ * else floor(x/delta)+1{alpha>=0}; xq (may be NULL) receives the clamped integer grid value x_quant. */
+int nq_adaround_forward(const float* x, const float* alpha, const float* delta, const float* zp, float* y, float* xq,
+                        int64_t rows, int64_t row_len, int per_row, int n_levels, int soft, nq_stream_t stream);
+
+/* d/dalpha of the soft forward, plus (reg_weight != 0) the gradient of the rounding regulariser
+ * reg_weight * sum(1 - |2h(alpha)-1|^reg_b) (calib_model.py:39-47).  dalpha is overwritten. */
+int nq_adaround_backward(const float* x, const float* gy, const float* alpha, const float* delta, const float* zp,
+                         float* dalpha, int64_t rows, int64_t row_len, int per_row, int n_levels, float reg_weight,
+                         float reg_b, nq_stream_t stream);
+
+/* Value of the regulariser over one alpha tensor: out[0] (+)= weight*sum(1-|2h-1|^b) (calib_model.py:45).
+ * ws: >= nq_reduce_ws_floats(n) floats of scratch; accumulate!=0 adds to out[0]. Deterministic. */
+int64_t nq_reduce_ws_floats(int64_t n);
+int nq_round_loss(const float* alpha, int64_t n, float b, float weight, float* ws, float* out, int accumulate,
+                  nq_stream_t stream);
+
+/* Gradient of the regulariser alone: dalpha (+)= gscale[0] * weight * d/dalpha sum(1-|2h-1|^b); gscale is a
+ * device scalar (the upstream gradient of the loss term) or NULL for 1. */
+int nq_round_loss_backward(const float* alpha, int64_t n, float b, float weight, const float* gscale, float* dalpha,
+                           int accumulate, nq_stream_t stream);
+
+/* torch.optim.Adam single-tensor step, no weight decay / amsgrad (used by calib_model.py:134, 195):
+ * m += (g-m)*(1-beta1); v = v*beta2 + (1-beta2)*g*g; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps),
+ * step_size = lr/(1-beta1^t), bc2_sqrt = sqrt(1-beta2^t) computed by the host in double. */
+int nq_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float beta1, float beta2,
+                 float eps, float bc2_sqrt, nq_stream_t stream);
+
+/* Orthonormal Walsh-Hadamard transform along the middle axis (hadamard_along_channel_weight,
+ * quant_layer.py:16-22, with the zero-padding of :45-49 and the slice of :71 folded in):
+ * x is [outer][n_in][inner] (read as zero for index >= n_in), y is [outer][n_out][inner], transform
+ * length n = 2^k <= 1024, n_in <= n, n_out <= n.  x and y must not alias. */
+int nq_fwht(const float* x, float* y, int64_t outer, int n, int64_t inner, int n_in, int n_out, nq_stream_t stream);
+
+/* ---------------------------------------------------------------- convolution side ------------ */
+
+/* Re-layout an OIHW weight (Cout,Cin,k,k) into the two GEMM operands the conv kernels read:
+ *   wt_fwd [krows_fwd][ld_fwd]: row (ci*k+kh)*k+kw, column co            (forward)
+ *   wt_bwd [krows_bwd][ld_bwd]: row (co*k+kh)*k+kw, column ci, taps flipped (data gradient)
+ * rows/columns beyond the real extents are written as zero.  Either output may be NULL. */
+int nq_weight_layouts(const float* w, float* wt_fwd, float* wt_bwd, int Cout, int Cin, int k, int krows_fwd,
+                      int ld_fwd, int krows_bwd, int ld_bwd, nq_stream_t stream);
+
+/* Padded operand sizes the conv kernels expect for a (Cin -> Cout, k) convolution. */
+int nq_conv_operand_dims(int Cin, int Cout, int k, int* krows, int* ld);
+
+/* Implicit-GEMM convolution on the fp32 MFMA pipe (replaces F.conv2d in QuantModule.forward,
+ * quant_layer.py:80, fused with what follows it in the decoder):
+ *   stride 1, padding k/2, x (B,Cin,H,W), wt = wt_fwd layout from nq_weight_layouts, bias (Cout) or NULL.
+ *   epilogue NQ_EPI_PLAIN     : y (B,Cout,H,W) = conv + bias
+ *            NQ_EPI_PS_GELU   : PixelShuffle(r) + exact-erf GELU (quant_block.py:31-35, _layers.py:20-36):
+ *                               z (B,Cout/r^2,H*r,W*r) = shuffled pre-activation, y = gelu(z)
+ *            NQ_EPI_TANH      : y = tanh(conv+bias)*0.5+0.5 (OutImg, _layers.py:10-16)
+ * The data gradient of a convolution is the same call with wt = wt_bwd and Cin/Cout swapped. */
+#define NQ_EPI_PLAIN 0
+#define NQ_EPI_PS_GELU 1
+#define NQ_EPI_TANH 2
+int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y, float* z, int B, int Cin, int H, int W,
+                    int Cout, int k, int krows, int ld, int r, int epilogue, nq_stream_t stream);
+
+/* Weight + bias gradient of the same convolution: dw (Cout,Cin,k,k), db (Cout) (db may be NULL),
+ * from x (B,Cin,H,W) and dy (B,Cout,H,W).  ws: scratch of >= nq_conv_wgrad_ws_floats(...) floats.
+ * Deterministic (fixed split-K order). */
+int64_t nq_conv_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
+int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+                  int k, nq_stream_t stream);
+
+/* Backward of PixelShuffle(r)+GELU: dconv (B,C*r*r,H,W) = unshuffle(da * gelu'(z)), da and z are (B,C,H*r,W*r). */
+int nq_ps_gelu_backward(const float* da, const float* z, float* dconv, int B, int C, int H, int W, int r,
+                        nq_stream_t stream);
+
+/* Backward of OutImg 'tanh': dconv = dimg * 0.5 * (1 - t^2), t = 2*img - 1. */
+int nq_tanh_out_backward(const float* dimg, const float* img, float* dconv, int64_t n, nq_stream_t stream);
+
+/* lp_loss p=2 (quantizer.py:66-71): loss[0] = sum_{b,c,h,w}(pred-tgt)^2 / (B*H*W); dpred (may be NULL) =
+ * 2*(pred-tgt)/(B*H*W) * gscale.  ws: >= nq_reduce_ws_floats(n) floats.  Deterministic. */
+int nq_l2_loss(const float* pred, const float* tgt, float* loss, float* dpred, float* ws, int64_t n, int64_t mean_count,
+               float gscale, nq_stream_t stream);
+
+/* Per-frame PSNR pieces (utils.py:148-151): sse[f] = sum over one frame of (out-gt)^2, frames of frame_len floats. */
+int nq_frame_sse(const float* out, const float* gt, float* sse, int64_t frames, int64_t frame_len, nq_stream_t stream);
+
+/* Frame gather: dst[i] = float(src_u8[idx[i]]) / 255 for frames of frame_len bytes (videosets/datasets.py:19-24);
+ * idx is a device int64 array of n entries. */
+int nq_gather_frames_u8(const uint8_t* src, const int64_t* idx, float* dst, int64_t n, int64_t frame_len,
+                        nq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NQ_HIP_H */

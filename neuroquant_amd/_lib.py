@@ -1,0 +1,78 @@
+"""ctypes binding of libnqhip.so (include/nq_hip.h).  There is no fallback: if the HIP library is
+missing the import of any op raises, loudly."""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnqhip.so")
+
+NQ_OK = 0
+EPI_PLAIN, EPI_PS_GELU, EPI_TANH = 0, 1, 2
+
+
+class NQLibraryError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise NQLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C neuroquant_amd/csrc`).  neuroquant_amd has no CPU/eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+    def sig(name, res, *args):
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    sig("nq_abi_version", I)
+    sig("nq_error_string", c_char_p, I)
+    sig("nq_scale_init_max", I, P, L, L, I, P, P, P)
+    sig("nq_uaq_forward", I, P, P, P, P, L, L, I, I, P)
+    sig("nq_uaq_backward", I, P, P, P, P, P, L, L, I, I, P)
+    sig("nq_adaround_init", I, P, P, P, P, P, P, L, L, I, P)
+    sig("nq_adaround_forward", I, P, P, P, P, P, P, L, L, I, I, I, P)
+    sig("nq_adaround_backward", I, P, P, P, P, P, P, L, L, I, I, F, F, P)
+    sig("nq_reduce_ws_floats", L, L)
+    sig("nq_round_loss", I, P, L, F, F, P, P, I, P)
+    sig("nq_round_loss_backward", I, P, L, F, F, P, P, I, P)
+    sig("nq_adam_step", I, P, P, P, P, L, F, F, F, F, F, P)
+    sig("nq_fwht", I, P, P, L, I, L, I, I, P)
+    sig("nq_weight_layouts", I, P, P, P, I, I, I, I, I, I, I, P)
+    sig("nq_conv_operand_dims", I, I, I, I, POINTER(c_int), POINTER(c_int))
+    sig("nq_conv_forward", I, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P)
+    sig("nq_conv_wgrad_ws_floats", L, I, I, I, I, I, I)
+    sig("nq_conv_wgrad", I, P, P, P, P, P, I, I, I, I, I, I, P)
+    sig("nq_ps_gelu_backward", I, P, P, P, I, I, I, I, I, P)
+    sig("nq_tanh_out_backward", I, P, P, P, L, P)
+    sig("nq_l2_loss", I, P, P, P, P, P, L, L, F, P)
+    sig("nq_frame_sse", I, P, P, P, L, L, P)
+    sig("nq_gather_frames_u8", I, P, P, P, L, L, P)
+    return lib
+
+
+EXPORTS = (
+    "nq_abi_version", "nq_error_string", "nq_scale_init_max", "nq_uaq_forward", "nq_uaq_backward",
+    "nq_adaround_init", "nq_adaround_forward", "nq_adaround_backward", "nq_reduce_ws_floats", "nq_round_loss", "nq_round_loss_backward",
+    "nq_adam_step", "nq_fwht", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward",
+    "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",
+    "nq_frame_sse", "nq_gather_frames_u8",
+)
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load()
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != NQ_OK:
+        msg = lib().nq_error_string(rc).decode()
+        raise NQLibraryError(f"libnqhip {what}: {msg} ({rc})")

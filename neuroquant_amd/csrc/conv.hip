@@ -1,0 +1,201 @@
+// C-ABI entry points of the convolution side: tile selection + dispatch to the per-kernel-size
+// implicit-GEMM / weight-gradient kernels, weight re-layout, split-K slab reduction.
+#include "nq_common.h"
+
+extern "C" {
+int nq_conv_igemm_k1(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int,
+                     hipStream_t);
+int nq_conv_igemm_k3(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int,
+                     hipStream_t);
+int nq_conv_igemm_k5(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int,
+                     hipStream_t);
+int nq_conv_wgrad_k1(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
+                     hipStream_t);
+int nq_conv_wgrad_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
+                     hipStream_t);
+int nq_conv_wgrad_k5(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
+                     hipStream_t);
+}
+
+namespace {
+
+constexpr int kMiOptions[] = {11, 10, 9, 8, 6, 5, 4, 3, 2, 1};
+
+inline int ci_per_slice(int k) { return k == 5 ? 4 : (k == 3 ? 8 : 16); }
+inline bool ks_ok(int k) { return k == 1 || k == 3 || k == 5; }
+
+// forward / data-gradient: fewest padded output channels, then the widest tile
+inline int pick_mi_fwd(int Cout) {
+  int best = 1, best_pad = 1 << 30;
+  for (int mi : kMiOptions) {
+    int mt = 16 * mi, pad = (Cout + mt - 1) / mt * mt;
+    if (pad < best_pad) {
+      best_pad = pad;
+      best = mi;
+    }
+  }
+  return best;
+}
+
+inline int wgrad_ni(int mi, int k) { return k == 1 ? 2 : (mi <= 3 ? 6 : (mi <= 6 ? 4 : 3)); }
+
+struct WgradPlan {
+  int mi, ni, co_pad, n_pad, nsplit;
+};
+
+inline WgradPlan plan_wgrad(int B, int Cin, int H, int W, int Cout, int k) {
+  WgradPlan p{};
+  int64_t best_cost = INT64_MAX;
+  const int N = Cin * k * k;
+  for (int mi : kMiOptions) {
+    int ni = wgrad_ni(mi, k);
+    int mt = 16 * mi, nt = 64 * ni;
+    int co_pad = (Cout + mt - 1) / mt * mt, n_pad = (N + nt - 1) / nt * nt;
+    int64_t cost = (int64_t)co_pad * n_pad;
+    if (cost < best_cost) {
+      best_cost = cost;
+      p.mi = mi;
+      p.ni = ni;
+      p.co_pad = co_pad;
+      p.n_pad = n_pad;
+    }
+  }
+  int tiles = (p.co_pad / (16 * p.mi)) * (p.n_pad / (64 * p.ni));
+  int nseg = ((W + 31) / 32) * H * B;
+  int ns = (768 + tiles - 1) / tiles;
+  if (ns > nseg) ns = nseg;
+  if (ns > 256) ns = 256;
+  if (ns < 1) ns = 1;
+  p.nsplit = ns;
+  return p;
+}
+
+__global__ __launch_bounds__(256) void weight_fwd_layout_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                                int Cout, int K, int krows, int ld) {
+  // wt[k][co] = w[co][k]  (k = (ci*KS+kh)*KS+kw is the OIHW inner index); 32x32 LDS transpose tile
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    int co = c0 + j, k = k0 + tx;
+    tile[j][tx] = (co < Cout && k < K) ? w[(int64_t)co * K + k] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    int k = k0 + j, co = c0 + tx;
+    if (k < krows && co < ld) wt[(int64_t)k * ld + co] = tile[tx][j];
+  }
+}
+
+__global__ __launch_bounds__(256) void weight_bwd_layout_kernel(const float* __restrict__ w, float* __restrict__ wt,
+                                                                int Cout, int Cin, int KK, int krows, int ld) {
+  // wt[(co*KK + tap')][ci] = w[co][ci][KK-1-tap']   (both spatial taps flipped)
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)krows * ld) return;
+  int row = (int)(i / ld), ci = (int)(i - (int64_t)row * ld);
+  int co = row / KK, tap = row - co * KK;
+  float v = 0.f;
+  if (co < Cout && ci < Cin) v = w[((int64_t)co * Cin + ci) * KK + (KK - 1 - tap)];
+  wt[i] = v;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ slab_db,
+                                                           float* __restrict__ dw, float* __restrict__ db, int Cout, int N,
+                                                           int co_pad, int n_pad, int nsplit) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)Cout * N;
+  if (i < total) {
+    int co = (int)(i / N), n = (int)(i - (int64_t)co * N);
+    const float* p = slab + (int64_t)co * n_pad + n;
+    const int64_t stride = (int64_t)co_pad * n_pad;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += p[k * stride];
+    dw[i] = s;
+  } else if (db && i < total + Cout) {
+    int co = (int)(i - total);
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab_db[(int64_t)k * co_pad + co];
+    db[co] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nq_conv_operand_dims(int Cin, int Cout, int k, int* krows, int* ld) {
+  if (!ks_ok(k) || Cin <= 0 || Cout <= 0 || !krows || !ld) return NQ_ERR_INVALID;
+  int ci = ci_per_slice(k);
+  *krows = (Cin + ci - 1) / ci * ci * k * k;
+  int mt = 16 * pick_mi_fwd(Cout);
+  *ld = (Cout + mt - 1) / mt * mt;
+  return NQ_OK;
+}
+
+int nq_weight_layouts(const float* w, float* wt_fwd, float* wt_bwd, int Cout, int Cin, int k, int krows_fwd, int ld_fwd,
+                      int krows_bwd, int ld_bwd, nq_stream_t stream) {
+  if (!w || Cout <= 0 || Cin <= 0 || k <= 0) return NQ_ERR_INVALID;
+  const int KK = k * k;
+  if (wt_fwd) {
+    if (krows_fwd < Cin * KK || ld_fwd < Cout) return NQ_ERR_INVALID;
+    dim3 g((unsigned)((krows_fwd + 31) / 32), (unsigned)((ld_fwd + 31) / 32));
+    hipLaunchKernelGGL(weight_fwd_layout_kernel, g, dim3(256), 0, nq_s(stream), w, wt_fwd, Cout, Cin * KK, krows_fwd,
+                       ld_fwd);
+  }
+  if (wt_bwd) {
+    if (krows_bwd < Cout * KK || ld_bwd < Cin) return NQ_ERR_INVALID;
+    int64_t total = (int64_t)krows_bwd * ld_bwd;
+    hipLaunchKernelGGL(weight_bwd_layout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nq_s(stream), w,
+                       wt_bwd, Cout, Cin, KK, krows_bwd, ld_bwd);
+  }
+  return nq_launch_status();
+}
+
+int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y, float* z, int B, int Cin, int H, int W,
+                    int Cout, int k, int krows, int ld, int r, int epilogue, nq_stream_t stream) {
+  if (!x || !wt || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
+  if (!ks_ok(k)) return NQ_ERR_UNSUPPORTED;
+  if (epilogue == NQ_EPI_PS_GELU && (!z || r <= 0 || Cout % (r * r) != 0)) return NQ_ERR_INVALID;
+  if (epilogue < 0 || epilogue > NQ_EPI_TANH) return NQ_ERR_INVALID;
+  int need_rows, need_ld;
+  nq_conv_operand_dims(Cin, Cout, k, &need_rows, &need_ld);
+  if (krows < need_rows || ld < need_ld || (ld & 3)) return NQ_ERR_INVALID;
+  if (B > 65535) return NQ_ERR_UNSUPPORTED;
+  const int mi = pick_mi_fwd(Cout);
+  hipStream_t st = nq_s(stream);
+  switch (k) {
+    case 1: return nq_conv_igemm_k1(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, st);
+    case 3: return nq_conv_igemm_k3(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, st);
+    default: return nq_conv_igemm_k5(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, st);
+  }
+}
+
+int64_t nq_conv_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
+  if (!ks_ok(k) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  WgradPlan p = plan_wgrad(B, Cin, H, W, Cout, k);
+  return (int64_t)p.nsplit * p.co_pad * ((int64_t)p.n_pad + 1);
+}
+
+int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+                  int k, nq_stream_t stream) {
+  if (!x || !dy || !dw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
+  if (!ks_ok(k)) return NQ_ERR_UNSUPPORTED;
+  WgradPlan p = plan_wgrad(B, Cin, H, W, Cout, k);
+  float* slab = ws;
+  float* slab_db = ws + (int64_t)p.nsplit * p.co_pad * p.n_pad;
+  hipStream_t st = nq_s(stream);
+  int rc;
+  switch (k) {
+    case 1: rc = nq_conv_wgrad_k1(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, st); break;
+    case 3: rc = nq_conv_wgrad_k3(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, st); break;
+    default: rc = nq_conv_wgrad_k5(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, st); break;
+  }
+  if (rc != NQ_OK) return rc;
+  const int N = Cin * k * k;
+  int64_t total = (int64_t)Cout * N + Cout;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slab, slab_db, dw, db, Cout,
+                     N, p.co_pad, p.n_pad, p.nsplit);
+  return nq_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,280 @@
+// Implicit-GEMM convolution on the fp32 MFMA pipe (v_mfma_f32_16x16x4_f32), stride 1, pad KS/2, NCHW.
+// Included once per kernel size (NQ_KS = 1, 3, 5) so the three sizes compile in parallel.
+//
+// GEMM view:  D[co][pixel] = sum_k  Wt[k][co] * Xpatch[k][pixel],   k = (ci, kh, kw)
+//   A operand = weights (MFMA rows = output channels), B operand = activations (MFMA columns = pixels), so
+//   the accumulator has 16 consecutive pixels of one row on 16 lanes (coalesced stores) and 4 consecutive
+//   output channels in the 4 registers of a lane (= the r*r sub-pixels of PixelShuffle for r=2).
+//
+// Workgroup = 4 waves = 4 image rows x 32 columns of one frame, all MT = 16*MI output channels of one
+// channel tile.  Wave w owns row w: 2 pixel blocks x MI channel blocks = 2*MI accumulators (8*MI VGPRs).
+//
+// K loop: a "slice" = CI input channels x KS taps of one kernel row kh.  The 4 lane groups (lane>>4) of the
+// 16x16x4 MFMA each walk their own CI/4 channels, so every LDS read is base-VGPR + immediate offset
+// (sum order over k is free in a GEMM).  Per slice the weights [CI*KS][MT] are streamed from the k-major
+// copy of the (fake-quantised) weight; the activation patch [CI][4+KS-1][32+KS-1] (zero-filled halo) is
+// staged once per channel group and reused for all KS kernel rows.  Both are double-buffered through
+// registers: global loads for slice s+1 are issued before the MFMAs of slice s, written to LDS after them,
+// one barrier per slice.  LDS plane/row strides are padded so that the two lane groups sharing an LDS
+// service cycle hit disjoint bank halves.
+//
+// Roofline: MFMA-bound (fp32 matrix peak 157.3 TFLOP/s); algorithmic flops = 2*Cout*Cin*KS^2*H*W*B.
+#include "nq_common.h"
+
+#ifndef NQ_KS
+#error "define NQ_KS before including conv_igemm_impl.h"
+#endif
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct ConvArgs {
+  const float* x;
+  const float* wt;
+  const float* bias;
+  float* y;
+  float* z;
+  int B, Cin, H, W, Cout, ld, r, epi, tiles_x, ncg;
+};
+
+constexpr int KS = NQ_KS;
+constexpr int KK = KS * KS;
+constexpr int PAD = KS / 2;
+constexpr int CI = (KS == 5) ? 4 : (KS == 3) ? 8 : 16;  // input channels per slice
+constexpr int CIQ = CI / 4;                              // channels per lane group
+constexpr int TH = 4, TW = 32;
+constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+constexpr int WROWS = CI * KS;  // weight rows per slice
+
+constexpr int pad_to_mod32(int v, int mult, int want) {  // smallest v' >= v with (mult*v') % 32 == want
+  while ((mult * v) % 32 != want) ++v;
+  return v;
+}
+constexpr int PS = pad_to_mod32(PH * PW, CIQ, 16);  // patch plane stride (floats)
+constexpr int PATCH_FLOATS = CI * PS;
+constexpr int PE = CI * PH * PW;               // patch elements to stage
+constexpr int PPT = (PE + 255) / 256;          // per thread
+
+__device__ __forceinline__ float gelu_exact(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+template <int MI>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int MT = 16 * MI;
+  // (CIQ*KS*LDW) % 32 == 16 and LDW % 4 == 0
+  constexpr int LDW = [] {
+    int v = MT;
+    while ((CIQ * KS * v) % 32 != 16 || (v % 4) != 0) ++v;
+    return v;
+  }();
+  constexpr int W_FLOATS = WROWS * LDW;
+  constexpr int WF4 = WROWS * (MT / 4);          // float4 loads per slice
+  constexpr int WPT = (WF4 + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const patch0 = smem;
+  float* const wl0 = smem + 2 * PATCH_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+  const int x0 = tile_x * TW, y0 = tile_y * TH;
+  const int co0 = blockIdx.y * MT;
+  const int b = blockIdx.z;
+  const int H = a.H, W = a.W, Cin = a.Cin;
+  const float* __restrict__ xb = a.x + (int64_t)b * Cin * H * W;
+  const float* __restrict__ wt = a.wt + co0;
+  const int ld = a.ld;
+
+  // ---- staging helpers ------------------------------------------------------------------------
+  float pv[PPT];
+  float4 wv[WPT];
+  // per-thread patch element coordinates are slice-invariant: precompute offsets (or -1 when outside the image)
+  int poff[PPT];   // offset inside one input plane, -1 = zero fill
+  int pci[PPT];    // channel inside the group
+  int plds[PPT];   // LDS offset
+#pragma unroll
+  for (int i = 0; i < PPT; ++i) {
+    int e = tid + i * 256;
+    int ci = e / (PH * PW), rem = e - ci * (PH * PW);
+    int r = rem / PW, c = rem - r * PW;
+    int gy = y0 - PAD + r, gx = x0 - PAD + c;
+    bool ok = (e < PE) && gy >= 0 && gy < H && gx >= 0 && gx < W;
+    poff[i] = ok ? gy * W + gx : -1;
+    pci[i] = ci;
+    plds[i] = (e < PE) ? ci * PS + r * PW + c : -1;
+  }
+  auto load_patch = [&](int cg) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+      int cig = cg * CI + pci[i];
+      pv[i] = (poff[i] >= 0 && cig < Cin) ? xb[(int64_t)cig * H * W + poff[i]] : 0.f;
+    }
+  };
+  auto store_patch = [&](float* dst) {
+#pragma unroll
+    for (int i = 0; i < PPT; ++i)
+      if (plds[i] >= 0) dst[plds[i]] = pv[i];
+  };
+  auto load_w = [&](int cg, int kh) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      int f = tid + i * 256;
+      if (f < WF4) {
+        int row = f / (MT / 4), c4 = f - row * (MT / 4);
+        int ci = row / KS, kw = row - ci * KS;
+        int grow = ((cg * CI + ci) * KS + kh) * KS + kw;
+        wv[i] = *reinterpret_cast<const float4*>(wt + (int64_t)grow * ld + c4 * 4);
+      }
+    }
+  };
+  auto store_w = [&](float* dst) {
+#pragma unroll
+    for (int i = 0; i < WPT; ++i) {
+      int f = tid + i * 256;
+      if (f < WF4) {
+        int row = f / (MT / 4), c4 = f - row * (MT / 4);
+        *reinterpret_cast<float4*>(dst + row * LDW + c4 * 4) = wv[i];
+      }
+    }
+  };
+
+  f32x4 acc[MI][2];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    acc[mi][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc[mi][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int a_base = (kq * CIQ * KS) * LDW + l16;
+  const int b_base = (kq * CIQ) * PS + wave * PW + l16;
+
+  // ---- prologue -------------------------------------------------------------------------------
+  const int nslices = a.ncg * KS;
+  load_patch(0);
+  load_w(0, 0);
+  store_patch(patch0);
+  store_w(wl0);
+  __syncthreads();
+
+  int cg = 0, kh = 0;
+  for (int s = 0; s < nslices; ++s) {
+    int ncg_ = cg, nkh = kh + 1;
+    if (nkh == KS) {
+      nkh = 0;
+      ncg_ = cg + 1;
+    }
+    const bool more = (s + 1 < nslices);
+    const bool new_patch = more && (nkh == 0);
+    if (more) load_w(ncg_, nkh);
+    if (new_patch) load_patch(ncg_);
+
+    const float* __restrict__ pb = patch0 + (cg & 1) * PATCH_FLOATS + b_base + kh * PW;
+    const float* __restrict__ wb = wl0 + (s & 1) * W_FLOATS + a_base;
+#pragma unroll
+    for (int t = 0; t < CIQ; ++t) {
+#pragma unroll
+      for (int kw = 0; kw < KS; ++kw) {
+        float bf0 = pb[t * PS + kw];
+        float bf1 = pb[t * PS + kw + 16];
+        float af[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) af[mi] = wb[(t * KS + kw) * LDW + mi * 16];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf0, acc[mi][0], 0, 0, 0);
+          acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf1, acc[mi][1], 0, 0, 0);
+        }
+      }
+    }
+    if (more) store_w(wl0 + ((s + 1) & 1) * W_FLOATS);
+    if (new_patch) store_patch(patch0 + (ncg_ & 1) * PATCH_FLOATS);
+    __syncthreads();
+    cg = ncg_;
+    kh = nkh;
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------
+  const int py = y0 + wave;
+  if (py >= H) return;
+  const int Cout = a.Cout;
+  const int epi = a.epi;
+  const int r = a.r, rr = a.r * a.r;
+  const int64_t HW = (int64_t)H * W;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      const int co = co0 + mi * 16 + 4 * kq + reg;
+      if (co >= Cout) continue;
+      const float bv = a.bias ? a.bias[co] : 0.f;
+      int c = 0, si = 0, sj = 0;
+      if (epi == NQ_EPI_PS_GELU) {
+        c = co / rr;
+        int rem = co - c * rr;
+        si = rem / r;
+        sj = rem - si * r;
+      }
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int px = x0 + ni * 16 + l16;
+        if (px >= W) continue;
+        float v = acc[mi][ni][reg] + bv;
+        if (epi == NQ_EPI_PS_GELU) {
+          const int C = Cout / rr;
+          int64_t o = (((int64_t)b * C + c) * (H * r) + (int64_t)py * r + si) * ((int64_t)W * r) + (int64_t)px * r + sj;
+          a.z[o] = v;
+          a.y[o] = gelu_exact(v);
+        } else {
+          int64_t o = ((int64_t)b * Cout + co) * HW + (int64_t)py * W + px;
+          a.y[o] = (epi == NQ_EPI_TANH) ? tanhf(v) * 0.5f + 0.5f : v;
+        }
+      }
+    }
+  }
+}
+
+template <int MI>
+int launch_igemm(const ConvArgs& a, int tiles, int co_tiles, hipStream_t st) {
+  constexpr int MT = 16 * MI;
+  constexpr int LDW = [] {
+    int v = MT;
+    while ((CIQ * KS * v) % 32 != 16 || (v % 4) != 0) ++v;
+    return v;
+  }();
+  size_t lds = (size_t)(2 * PATCH_FLOATS + 2 * WROWS * LDW) * sizeof(float);
+  hipLaunchKernelGGL(conv_igemm_kernel<MI>, dim3((unsigned)tiles, (unsigned)co_tiles, (unsigned)a.B), dim3(256), lds, st,
+                     a);
+  return nq_launch_status();
+}
+
+}  // namespace
+
+#define NQ_CAT2(a, b) a##b
+#define NQ_CAT(a, b) NQ_CAT2(a, b)
+
+// mi_sel: channel blocks (of 16) per workgroup, chosen by nq_conv_pick_mi().
+extern "C" int NQ_CAT(nq_conv_igemm_k, NQ_KS)(const float* x, const float* wt, const float* bias, float* y, float* z,
+                                               int B, int Cin, int H, int W, int Cout, int ld, int r, int epi,
+                                               int mi_sel, hipStream_t st) {
+  ConvArgs a;
+  a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.z = z;
+  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.ld = ld; a.r = r; a.epi = epi;
+  a.tiles_x = (W + TW - 1) / TW;
+  a.ncg = (Cin + CI - 1) / CI;
+  int tiles = a.tiles_x * ((H + TH - 1) / TH);
+  int co_tiles = (Cout + 16 * mi_sel - 1) / (16 * mi_sel);
+  switch (mi_sel) {
+    case 1: return launch_igemm<1>(a, tiles, co_tiles, st);
+    case 2: return launch_igemm<2>(a, tiles, co_tiles, st);
+    case 3: return launch_igemm<3>(a, tiles, co_tiles, st);
+    case 4: return launch_igemm<4>(a, tiles, co_tiles, st);
+    case 5: return launch_igemm<5>(a, tiles, co_tiles, st);
+    case 6: return launch_igemm<6>(a, tiles, co_tiles, st);
+    case 8: return launch_igemm<8>(a, tiles, co_tiles, st);
+    case 9: return launch_igemm<9>(a, tiles, co_tiles, st);
+    case 10: return launch_igemm<10>(a, tiles, co_tiles, st);
+    case 11: return launch_igemm<11>(a, tiles, co_tiles, st);
+    default: return NQ_ERR_UNSUPPORTED;
+  }
+}

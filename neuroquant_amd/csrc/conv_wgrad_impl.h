@@ -1,0 +1,227 @@
+// Weight/bias gradient of the stride-1 convolution on the fp32 MFMA pipe (v_mfma_f32_16x16x4_f32).
+// Included once per kernel size (NQ_KS = 1, 3, 5).
+//
+// GEMM view:  dW[co][n] = sum_pixels  dY[co][p] * X[n][p],   n = (ci, kh, kw) = the OIHW inner index,
+//   X[n][p] = x[ci][py + kh - pad][px + kw - pad].  K dimension = pixels (B*H*W): split across workgroups,
+//   each writes a partial [co][n] slab; a second kernel sums the slabs in fixed order (deterministic).
+//
+// Workgroup = 4 waves; tile = MT = 16*MI output channels x NT = 64*NI n-values; wave w owns n-columns
+// [w*16*NI, (w+1)*16*NI) for all MT channels: MI*NI accumulators.  It walks "segments" = 32 consecutive
+// pixels of one image row: stages dY[MT][32] and the x rows [CIT][KS][32+KS-1] in LDS, then 8 MFMA k-steps.
+// Lane j of a B fragment is one n = (ci,kh,kw): its LDS address is a per-lane constant + the pixel offset,
+// and the LDS strides are chosen (row stride == KS, plane stride == KS*KS mod 32) so bank(n) = n mod 32.
+// The bias gradient (row sums of dY) is accumulated by the n-tile-0 workgroups from the staged dY tile.
+//
+// Roofline: MFMA-bound; algorithmic flops = 2*Cout*Cin*KS^2*H*W*B.
+#include "nq_common.h"
+
+#ifndef NQ_KS
+#error "define NQ_KS before including conv_wgrad_impl.h"
+#endif
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct WgradArgs {
+  const float* x;
+  const float* dy;
+  float* slab;     // [nsplit][co_pad][n_pad]
+  float* slab_db;  // [nsplit][co_pad]
+  int B, Cin, H, W, Cout, N, co_pad, n_pad, segs_x, nseg, nsplit;
+};
+
+constexpr int KS = NQ_KS;
+constexpr int KK = KS * KS;
+constexpr int PAD = KS / 2;
+constexpr int SEG = 32;
+constexpr int LDP = 33;  // dY tile row stride
+constexpr int PWS = [] {  // x row stride: >= SEG+KS-1 and == KS (mod 32)
+  int v = SEG + KS - 1;
+  while (v % 32 != KS % 32) ++v;
+  return v;
+}();
+constexpr int PSX = KS * PWS;  // plane stride (== KS*KS mod 32)
+
+template <int MI, int NI>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int MT = 16 * MI, NT = 64 * NI;
+  constexpr int CIT = (NT + KK - 2) / KK + 1;  // max input channels spanned by an n-tile
+  constexpr int DZ_FLOATS = MT * LDP;
+  constexpr int XE = CIT * KS * (SEG + KS - 1);  // x elements staged per segment
+  constexpr int XPT = (XE + 255) / 256;
+  constexpr int DE = MT * SEG;
+  constexpr int DPT = (DE + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* const dzl = smem;
+  float* const xl = smem + DZ_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int split = blockIdx.x;
+  const int n0 = blockIdx.y * NT;
+  const int co0 = blockIdx.z * MT;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, N = a.N;
+  const int ci0 = n0 / KK;
+  const int64_t HW = (int64_t)H * W;
+
+  // per-lane B-fragment constants
+  int lc[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    int n = n0 + (wave * NI + ni) * 16 + l16;
+    if (n > N - 1) n = N - 1;  // padding columns recompute the last one; discarded at the store
+    int ci = n / KK, rem = n - ci * KK;
+    int kh = rem / KS, kw = rem - kh * KS;
+    lc[ni] = (ci - ci0) * PSX + kh * PWS + kw;
+  }
+  const int pxo = ((kq & 1) << 4) + ((kq >> 1) << 3);
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float db_acc = 0.f;
+  const bool do_db = (blockIdx.y == 0) && a.slab_db != nullptr;
+
+  const int seg_lo = (int)(((int64_t)a.nseg * split) / a.nsplit);
+  const int seg_hi = (int)(((int64_t)a.nseg * (split + 1)) / a.nsplit);
+
+  float dv[DPT], xv[XPT];
+  auto load_seg = [&](int seg) {
+    const int xs = seg % a.segs_x;
+    const int by = seg / a.segs_x;
+    const int y = by % H, b = by / H;
+    const int x0 = xs * SEG;
+    // keep the per-element index math inside the loop (recomputed per segment, ~10 VALU each) instead of letting
+    // LICM hoist ~100 VGPRs of invariants across the MFMA loop
+    int t = tid;
+    asm volatile("" : "+v"(t));
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      int e = t + i * 256;
+      int co = e / SEG, px = e - co * SEG;
+      int gco = co0 + co, gx = x0 + px;
+      bool ok = (e < DE) && gco < Cout && gx < W;
+      dv[i] = ok ? a.dy[((int64_t)b * Cout + gco) * HW + (int64_t)y * W + gx] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      int e = t + i * 256;
+      int ci = e / (KS * (SEG + KS - 1)), rem = e - ci * (KS * (SEG + KS - 1));
+      int r = rem / (SEG + KS - 1), c = rem - r * (SEG + KS - 1);
+      int gci = ci0 + ci, gy = y - PAD + r, gx = x0 - PAD + c;
+      bool ok = (e < XE) && gci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      xv[i] = ok ? a.x[((int64_t)b * Cin + gci) * HW + (int64_t)gy * W + gx] : 0.f;
+    }
+  };
+  auto store_seg = [&]() {
+    int t = tid;
+    asm volatile("" : "+v"(t));
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      int e = t + i * 256;
+      if (e < DE) {
+        int co = e / SEG, px = e - co * SEG;
+        dzl[co * LDP + px] = dv[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XPT; ++i) {
+      int e = t + i * 256;
+      if (e < XE) {
+        int ci = e / (KS * (SEG + KS - 1)), rem = e - ci * (KS * (SEG + KS - 1));
+        int r = rem / (SEG + KS - 1), c = rem - r * (SEG + KS - 1);
+        xl[ci * PSX + r * PWS + c] = xv[i];
+      }
+    }
+  };
+
+  if (seg_lo < seg_hi) load_seg(seg_lo);
+  for (int seg = seg_lo; seg < seg_hi; ++seg) {
+    __syncthreads();  // previous segment's readers are done
+    store_seg();
+    __syncthreads();
+    if (seg + 1 < seg_hi) load_seg(seg + 1);  // in flight under the MFMAs below
+    // ---- 8 k-steps of 4 pixels ----
+#pragma unroll 2
+    for (int s = 0; s < 8; ++s) {
+      float bf[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) bf[ni] = xl[lc[ni] + pxo + s];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        float af = dzl[(mi * 16 + l16) * LDP + pxo + s];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    if (do_db && tid < MT) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int px = 0; px < SEG; ++px) sacc += dzl[tid * LDP + px];
+      db_acc += sacc;
+    }
+  }
+
+  // ---- write the partial slab ----
+  float* __restrict__ slab = a.slab + (int64_t)split * a.co_pad * a.n_pad;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      int n = n0 + (wave * NI + ni) * 16 + l16;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        int co = co0 + mi * 16 + 4 * kq + reg;
+        slab[(int64_t)co * a.n_pad + n] = acc[mi][ni][reg];
+      }
+    }
+  if (do_db && tid < MT) a.slab_db[(int64_t)split * a.co_pad + co0 + tid] = db_acc;
+}
+
+constexpr int ni_for(int mi) { return KS == 1 ? 2 : (mi <= 3 ? 6 : (mi <= 6 ? 4 : 3)); }
+
+template <int MI, int NI>
+int launch_wgrad(const WgradArgs& a, hipStream_t st) {
+  constexpr int MT = 16 * MI, NT = 64 * NI;
+  constexpr int CIT = (NT + KK - 2) / KK + 1;
+  size_t lds = (size_t)(MT * LDP + CIT * PSX) * sizeof(float);
+  dim3 grid((unsigned)a.nsplit, (unsigned)(a.n_pad / NT), (unsigned)(a.co_pad / MT));
+  hipLaunchKernelGGL((conv_wgrad_kernel<MI, NI>), grid, dim3(256), lds, st, a);
+  return nq_launch_status();
+}
+
+}  // namespace
+
+#define NQ_CAT2(a, b) a##b
+#define NQ_CAT(a, b) NQ_CAT2(a, b)
+
+// (mi_sel, ni_sel) chosen by nq_wgrad_pick(); co_pad % (16*mi) == 0 and n_pad % (64*ni) == 0.
+extern "C" int NQ_CAT(nq_conv_wgrad_k, NQ_KS)(const float* x, const float* dy, float* slab, float* slab_db, int B,
+                                               int Cin, int H, int W, int Cout, int co_pad, int n_pad, int nsplit,
+                                               int mi_sel, int ni_sel, hipStream_t st) {
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.slab = slab; a.slab_db = slab_db;
+  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.N = Cin * KK;
+  a.co_pad = co_pad; a.n_pad = n_pad;
+  a.segs_x = (W + SEG - 1) / SEG;
+  a.nseg = a.segs_x * H * B;
+  a.nsplit = nsplit;
+#define NQ_WG_CASE(MI_) \
+  if (mi_sel == MI_ && ni_sel == ni_for(MI_)) return launch_wgrad<MI_, ni_for(MI_)>(a, st);
+  NQ_WG_CASE(1)
+  NQ_WG_CASE(2)
+  NQ_WG_CASE(3)
+  NQ_WG_CASE(4)
+  NQ_WG_CASE(5)
+  NQ_WG_CASE(6)
+  NQ_WG_CASE(8)
+  NQ_WG_CASE(9)
+  NQ_WG_CASE(10)
+  NQ_WG_CASE(11)
+#undef NQ_WG_CASE
+  return NQ_ERR_UNSUPPORTED;
+}

@@ -1,0 +1,162 @@
+// Activation-side elementwise / reduction kernels around the convolutions (HBM-bound):
+// PixelShuffle+GELU backward, OutImg(tanh) backward, L2 reconstruction loss (+gradient),
+// per-frame squared error for PSNR, uint8 frame gather.
+#include "nq_common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+// d/dv gelu(v), exact-erf form (nn.GELU(), models/_layers.py:104-105)
+__device__ __forceinline__ float gelu_grad(float v) {
+  const float kAlpha = 0.70710678118654752440f;        // 1/sqrt(2)
+  const float kBeta = 0.39894228040143267794f;         // 1/sqrt(2*pi)
+  float cdf = 0.5f * (1.0f + erff(v * kAlpha));
+  float pdf = kBeta * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
+// One workgroup per (b, c, y): reads the r rows Y = y*r+i of da / z (each W*r contiguous floats) and scatters
+// to the r*r planes of dconv.  R = 0 -> runtime r.
+template <int R>
+__global__ __launch_bounds__(TPB) void ps_gelu_bwd_kernel(const float* __restrict__ da, const float* __restrict__ z,
+                                                          float* __restrict__ dconv, int C, int H, int W, int r_rt) {
+  const int r = R ? R : r_rt;
+  const int64_t bcy = blockIdx.x;  // ((b*C + c)*H + y)
+  const int y = (int)(bcy % H);
+  const int64_t bc = bcy / H;
+  const int Wr = W * r;
+  const int64_t in_base = (bc * (int64_t)(H * r) + (int64_t)y * r) * Wr;  // row Y = y*r of plane (b,c)
+  const int64_t out_plane = (int64_t)H * W;
+  const int64_t out_base = (bc * (r * r)) * out_plane + (int64_t)y * W;
+  const int total = r * Wr;
+  for (int e = threadIdx.x; e < total; e += TPB) {
+    int i = e / Wr, X = e - i * Wr;
+    int x = X / r, j = X - x * r;
+    float g = da[in_base + e] * gelu_grad(z[in_base + e]);
+    dconv[out_base + (int64_t)(i * r + j) * out_plane + x] = g;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void tanh_out_bwd_kernel(const float* __restrict__ dimg, const float* __restrict__ img,
+                                                           float* __restrict__ dconv, int64_t n) {
+  int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 g = *reinterpret_cast<const float4*>(dimg + i);
+    float4 o = *reinterpret_cast<const float4*>(img + i);
+    float4 r;
+    float t;
+    t = 2.f * o.x - 1.f; r.x = g.x * 0.5f * (1.f - t * t);
+    t = 2.f * o.y - 1.f; r.y = g.y * 0.5f * (1.f - t * t);
+    t = 2.f * o.z - 1.f; r.z = g.z * 0.5f * (1.f - t * t);
+    t = 2.f * o.w - 1.f; r.w = g.w * 0.5f * (1.f - t * t);
+    *reinterpret_cast<float4*>(dconv + i) = r;
+  } else {
+    for (; i < n; ++i) {
+      float t = 2.f * img[i] - 1.f;
+      dconv[i] = dimg[i] * 0.5f * (1.f - t * t);
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void l2_loss_stage1(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                      float* __restrict__ dpred, float* __restrict__ ws, int64_t n,
+                                                      float gcoef) {
+  __shared__ float red[16];
+  int64_t i0 = (int64_t)blockIdx.x * NQ_RED_CHUNK;
+  float acc = 0.f;
+#pragma unroll 4
+  for (int k = 0; k < NQ_RED_CHUNK / TPB; ++k) {
+    int64_t i = i0 + k * TPB + threadIdx.x;
+    if (i < n) {
+      float d = pred[i] - tgt[i];
+      acc += d * d;
+      if (dpred) dpred[i] = gcoef * d;
+    }
+  }
+  float s = nq_block_sum(acc, red);
+  if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(1024) void frame_sse_kernel(const float* __restrict__ out, const float* __restrict__ gt,
+                                                         float* __restrict__ sse, int64_t frame_len) {
+  __shared__ float red[16];
+  const float* a = out + (int64_t)blockIdx.x * frame_len;
+  const float* b = gt + (int64_t)blockIdx.x * frame_len;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < frame_len; i += 1024) {
+    float d = a[i] - b[i];
+    acc += d * d;
+  }
+  float s = nq_block_sum(acc, red);
+  if (threadIdx.x == 0) sse[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(TPB) void gather_u8_kernel(const uint8_t* __restrict__ src, const int64_t* __restrict__ idx,
+                                                        float* __restrict__ dst, int64_t frame_len) {
+  const int64_t f = blockIdx.y;
+  const uint8_t* s = src + idx[f] * frame_len;
+  float* d = dst + f * frame_len;
+  int64_t i = ((int64_t)blockIdx.x * TPB + threadIdx.x) * 4;
+  if (i + 3 < frame_len && ((reinterpret_cast<uintptr_t>(s + i) & 3) == 0)) {
+    uchar4 v = *reinterpret_cast<const uchar4*>(s + i);
+    float4 o = make_float4((float)v.x / 255.f, (float)v.y / 255.f, (float)v.z / 255.f, (float)v.w / 255.f);
+    *reinterpret_cast<float4*>(d + i) = o;
+  } else {
+    for (int k = 0; k < 4 && i + k < frame_len; ++k) d[i + k] = (float)s[i + k] / 255.f;  // img / 255. (datasets.py:23)
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nq_ps_gelu_backward(const float* da, const float* z, float* dconv, int B, int C, int H, int W, int r,
+                        nq_stream_t stream) {
+  if (!da || !z || !dconv || B <= 0 || C <= 0 || H <= 0 || W <= 0 || r <= 0) return NQ_ERR_INVALID;
+  int64_t blocks = (int64_t)B * C * H;
+  if (blocks > 0x7fffffffLL) return NQ_ERR_UNSUPPORTED;
+  dim3 g((unsigned)blocks), b(TPB);
+  switch (r) {
+    case 1: hipLaunchKernelGGL(ps_gelu_bwd_kernel<1>, g, b, 0, nq_s(stream), da, z, dconv, C, H, W, r); break;
+    case 2: hipLaunchKernelGGL(ps_gelu_bwd_kernel<2>, g, b, 0, nq_s(stream), da, z, dconv, C, H, W, r); break;
+    case 4: hipLaunchKernelGGL(ps_gelu_bwd_kernel<4>, g, b, 0, nq_s(stream), da, z, dconv, C, H, W, r); break;
+    case 5: hipLaunchKernelGGL(ps_gelu_bwd_kernel<5>, g, b, 0, nq_s(stream), da, z, dconv, C, H, W, r); break;
+    default: hipLaunchKernelGGL(ps_gelu_bwd_kernel<0>, g, b, 0, nq_s(stream), da, z, dconv, C, H, W, r); break;
+  }
+  return nq_launch_status();
+}
+
+int nq_tanh_out_backward(const float* dimg, const float* img, float* dconv, int64_t n, nq_stream_t stream) {
+  if (!dimg || !img || !dconv || n <= 0) return NQ_ERR_INVALID;
+  int64_t blocks = (n + TPB * 4 - 1) / (TPB * 4);
+  hipLaunchKernelGGL(tanh_out_bwd_kernel, dim3((unsigned)blocks), dim3(TPB), 0, nq_s(stream), dimg, img, dconv, n);
+  return nq_launch_status();
+}
+
+int nq_l2_loss(const float* pred, const float* tgt, float* loss, float* dpred, float* ws, int64_t n, int64_t mean_count,
+               float gscale, nq_stream_t stream) {
+  if (!pred || !tgt || !loss || !ws || n <= 0 || mean_count <= 0) return NQ_ERR_INVALID;
+  int64_t parts = (n + NQ_RED_CHUNK - 1) / NQ_RED_CHUNK;
+  float gcoef = (float)(2.0 / (double)mean_count) * gscale;
+  hipLaunchKernelGGL(l2_loss_stage1, dim3((unsigned)parts), dim3(TPB), 0, nq_s(stream), pred, tgt, dpred, ws, n, gcoef);
+  hipLaunchKernelGGL(nq_sum_stage2, dim3(1), dim3(256), 0, nq_s(stream), ws, parts, (float)(1.0 / (double)mean_count),
+                     loss, 0);
+  return nq_launch_status();
+}
+
+int nq_frame_sse(const float* out, const float* gt, float* sse, int64_t frames, int64_t frame_len, nq_stream_t stream) {
+  if (!out || !gt || !sse || frames <= 0 || frame_len <= 0) return NQ_ERR_INVALID;
+  hipLaunchKernelGGL(frame_sse_kernel, dim3((unsigned)frames), dim3(1024), 0, nq_s(stream), out, gt, sse, frame_len);
+  return nq_launch_status();
+}
+
+int nq_gather_frames_u8(const uint8_t* src, const int64_t* idx, float* dst, int64_t n, int64_t frame_len,
+                        nq_stream_t stream) {
+  if (!src || !idx || !dst || n <= 0 || frame_len <= 0 || n > 65535) return NQ_ERR_INVALID;
+  dim3 g((unsigned)((frame_len + TPB * 4 - 1) / (TPB * 4)), (unsigned)n);
+  hipLaunchKernelGGL(gather_u8_kernel, g, dim3(TPB), 0, nq_s(stream), src, idx, dst, frame_len);
+  return nq_launch_status();
+}
+
+}  // extern "C"

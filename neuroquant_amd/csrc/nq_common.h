@@ -1,0 +1,62 @@
+// Shared device/host helpers for libnqhip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/nq_hip.h"
+
+#define NQ_WAVE 64
+
+static inline int nq_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? NQ_OK : NQ_ERR_LAUNCH;
+}
+
+static inline hipStream_t nq_s(nq_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- wave / block reductions (wave = 64 lanes) ----
+__device__ __forceinline__ float nq_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float nq_wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float nq_wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+  return v;
+}
+
+// Block-wide sum for blockDim.x <= 1024 (multiple of 64). Result valid in thread 0. Fixed order -> deterministic.
+__device__ __forceinline__ float nq_block_sum(float v, float* smem /* >= 16 floats */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  v = nq_wave_sum(v);
+  __syncthreads();
+  if (lane == 0) smem[wave] = v;
+  __syncthreads();
+  float r = 0.f;
+  if (threadIdx.x == 0)
+    for (int i = 0; i < nw; ++i) r += smem[i];
+  return r;
+}
+
+// Rectified-sigmoid constants of AdaRound (quantizer.py:274)
+#define NQ_GAMMA (-0.1f)
+#define NQ_ZETA (1.1f)
+
+__device__ __forceinline__ float nq_sigmoid(float a) { return 1.0f / (1.0f + expf(-a)); }
+
+// Stage 2 of the deterministic two-stage sums: out[0] = (accumulate ? out[0] : 0) + scale * sum(ws[0..nparts)).
+static __global__ __launch_bounds__(256) void nq_sum_stage2(const float* __restrict__ ws, int64_t nparts, float scale,
+                                                           float* __restrict__ out, int accumulate) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < nparts; i += 256) acc += ws[i];
+  float s = nq_block_sum(acc, red);
+  if (threadIdx.x == 0) out[0] = (accumulate ? out[0] : 0.f) + s * scale;
+}
+#define NQ_RED_CHUNK 4096  // elements per stage-1 block (256 threads x 16)

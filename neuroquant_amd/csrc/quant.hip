@@ -1,0 +1,336 @@
+// Parameter-side kernels: scale init, uniform-affine and AdaRound fake-quant (forward / backward),
+// rounding regulariser, Adam.  All HBM-bound elementwise / row-reduction work; compiled with
+// -ffp-contract=off so that the arithmetic is the reference's op-by-op fp32 sequence
+// (quantization/quantizer.py, calib_model.py:39-47).
+#include "nq_common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+constexpr int EPT = 4;  // elements per thread per block chunk
+
+// ------------------------------------------------------------------------------------------------
+// scale init: one workgroup per row (quantizer.py:156-168)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void scale_init_kernel(const float* __restrict__ x, int64_t row_len, int n_levels,
+                                                         float* __restrict__ delta, float* __restrict__ zp) {
+  __shared__ float smin[4], smax[4];
+  const float* xr = x + (int64_t)blockIdx.x * row_len;
+  float mn = 0.f, mx = 0.f;  // min(x_min, 0), max(x_max, 0)
+  for (int64_t i = threadIdx.x; i < row_len; i += TPB) {
+    float v = xr[i];
+    mn = fminf(mn, v);
+    mx = fmaxf(mx, v);
+  }
+  mn = nq_wave_min(mn);
+  mx = nq_wave_max(mx);
+  if ((threadIdx.x & 63) == 0) {
+    smin[threadIdx.x >> 6] = mn;
+    smax[threadIdx.x >> 6] = mx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < TPB / 64; ++i) {
+      mn = fminf(mn, smin[i]);
+      mx = fmaxf(mx, smax[i]);
+    }
+    // Python-double division, then cast to fp32 (quantizer.py:163)
+    float d = (float)(((double)mx - (double)mn) / (double)(n_levels - 1));
+    d = fmaxf(d, 1e-8f);
+    delta[blockIdx.x] = d;
+    zp[blockIdx.x] = rintf((-mn) / d);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// UAQ forward / backward
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void uaq_fwd_kernel(const float* __restrict__ x, const float* __restrict__ delta,
+                                                      const float* __restrict__ zp, float* __restrict__ y,
+                                                      int64_t row_len, int per_row, float qmax) {
+  const int64_t row = blockIdx.y;
+  const float d = per_row ? delta[row] : delta[0];
+  const float z = per_row ? zp[row] : zp[0];
+  const int64_t base = row * row_len;
+  int64_t i = (int64_t)blockIdx.x * (TPB * EPT) + threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e, i += TPB) {
+    if (i < row_len) {
+      float xi = rintf(x[base + i] / d) + z;
+      float xq = fminf(fmaxf(xi, 0.f), qmax);
+      y[base + i] = (xq - z) * d;
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void uaq_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                      const float* __restrict__ delta, const float* __restrict__ zp,
+                                                      float* __restrict__ ddelta, int64_t row_len, int per_row,
+                                                      float qmax) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  const float d = per_row ? delta[row] : delta[0];
+  const float z = per_row ? zp[row] : zp[0];
+  const int64_t base = row * row_len;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < row_len; i += TPB) {
+    float u = x[base + i] / d;
+    float xi = rintf(u) + z;
+    float xq = fminf(fmaxf(xi, 0.f), qmax);
+    float inside = (xi >= 0.f && xi <= qmax) ? 1.f : 0.f;
+    acc += gy[base + i] * ((xq - z) - inside * u);
+  }
+  float s = nq_block_sum(acc, red);
+  if (threadIdx.x == 0) ddelta[row] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AdaRound
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_round_trip(float v) { return (float)(_Float16)v; }  // round-to-nearest-even, like Tensor.half()
+
+__global__ void adaround_scale_kernel(const float* __restrict__ din, const float* __restrict__ zin,
+                                      float* __restrict__ dout, float* __restrict__ zout, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    dout[i] = half_round_trip(din[i]);  // quantizer.py:264
+    zout[i] = half_round_trip(zin[i]);  // quantizer.py:265
+  }
+}
+
+__global__ __launch_bounds__(TPB) void adaround_alpha_init_kernel(const float* __restrict__ x,
+                                                                  const float* __restrict__ delta,
+                                                                  float* __restrict__ alpha, int64_t row_len,
+                                                                  int per_row) {
+  const int64_t row = blockIdx.y;
+  const float d = per_row ? delta[row] : delta[0];
+  const int64_t base = row * row_len;
+  int64_t i = (int64_t)blockIdx.x * (TPB * EPT) + threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e, i += TPB) {
+    if (i < row_len) {
+      float u = x[base + i] / d;
+      float rest = u - floorf(u);
+      alpha[base + i] = -logf((NQ_ZETA - NQ_GAMMA) / (rest - NQ_GAMMA) - 1.0f);  // quantizer.py:312
+    }
+  }
+}
+
+__device__ __forceinline__ float soft_target_lin(float a) { return nq_sigmoid(a) * (NQ_ZETA - NQ_GAMMA) + NQ_GAMMA; }
+
+__global__ __launch_bounds__(TPB) void adaround_fwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
+                                                           const float* __restrict__ delta,
+                                                           const float* __restrict__ zp, float* __restrict__ y,
+                                                           float* __restrict__ xq_out, int64_t row_len, int per_row,
+                                                           float qmax, int soft) {
+  const int64_t row = blockIdx.y;
+  const float d = per_row ? delta[row] : delta[0];
+  const float z = per_row ? zp[row] : zp[0];
+  const int64_t base = row * row_len;
+  int64_t i = (int64_t)blockIdx.x * (TPB * EPT) + threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e, i += TPB) {
+    if (i < row_len) {
+      float a = alpha[base + i];
+      float h = soft ? fminf(fmaxf(soft_target_lin(a), 0.f), 1.f) : (a >= 0.f ? 1.f : 0.f);
+      float xi = (floorf(x[base + i] / d) + h) + z;
+      float xq = fminf(fmaxf(xi, 0.f), qmax);
+      y[base + i] = (xq - z) * d;
+      if (xq_out) xq_out[base + i] = xq;
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void adaround_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                           const float* __restrict__ alpha,
+                                                           const float* __restrict__ delta,
+                                                           const float* __restrict__ zp, float* __restrict__ dalpha,
+                                                           int64_t row_len, int per_row, float qmax, float reg_weight,
+                                                           float reg_b) {
+  const int64_t row = blockIdx.y;
+  const float d = per_row ? delta[row] : delta[0];
+  const float z = per_row ? zp[row] : zp[0];
+  const int64_t base = row * row_len;
+  int64_t i = (int64_t)blockIdx.x * (TPB * EPT) + threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e, i += TPB) {
+    if (i < row_len) {
+      float a = alpha[base + i];
+      float s = nq_sigmoid(a);
+      float lin = s * (NQ_ZETA - NQ_GAMMA) + NQ_GAMMA;
+      float h = fminf(fmaxf(lin, 0.f), 1.f);
+      float hp = (lin >= 0.f && lin <= 1.f) ? (NQ_ZETA - NQ_GAMMA) * (s * (1.f - s)) : 0.f;
+      float xi = (floorf(x[base + i] / d) + h) + z;
+      float inside = (xi >= 0.f && xi <= qmax) ? 1.f : 0.f;
+      float g = gy[base + i] * d * inside * hp;
+      if (reg_weight != 0.f) {
+        // R = w * sum(1 - (2|h-.5|)^b);  dR/dh = -w * b * (2|h-.5|)^(b-1) * 2 * sign(h-.5)
+        float c = h - 0.5f;
+        float t = fabsf(c) * 2.f;
+        float sg = (c > 0.f) ? 1.f : ((c < 0.f) ? -1.f : 0.f);
+        float dRdh = -reg_weight * (reg_b * powf(t, reg_b - 1.f)) * 2.f * sg;
+        g += dRdh * hp;
+      }
+      dalpha[base + i] = g;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// deterministic two-stage sums
+// ------------------------------------------------------------------------------------------------
+constexpr int RED_CHUNK = NQ_RED_CHUNK;
+
+__global__ __launch_bounds__(TPB) void round_loss_stage1(const float* __restrict__ alpha, int64_t n, float b,
+                                                         float* __restrict__ ws) {
+  __shared__ float red[16];
+  int64_t i0 = (int64_t)blockIdx.x * RED_CHUNK;
+  float acc = 0.f;
+  for (int k = 0; k < 16; ++k) {
+    int64_t i = i0 + k * TPB + threadIdx.x;
+    if (i < n) {
+      float h = fminf(fmaxf(soft_target_lin(alpha[i]), 0.f), 1.f);
+      acc += 1.f - powf(fabsf(h - 0.5f) * 2.f, b);
+    }
+  }
+  float s = nq_block_sum(acc, red);
+  if (threadIdx.x == 0) ws[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(TPB) void round_loss_bwd_kernel(const float* __restrict__ alpha, int64_t n, float b,
+                                                             float weight, const float* __restrict__ gscale,
+                                                             float* __restrict__ dalpha, int accumulate) {
+  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  float s = nq_sigmoid(alpha[i]);
+  float lin = s * (NQ_ZETA - NQ_GAMMA) + NQ_GAMMA;
+  float h = fminf(fmaxf(lin, 0.f), 1.f);
+  float hp = (lin >= 0.f && lin <= 1.f) ? (NQ_ZETA - NQ_GAMMA) * (s * (1.f - s)) : 0.f;
+  float c = h - 0.5f;
+  float sg = (c > 0.f) ? 1.f : ((c < 0.f) ? -1.f : 0.f);
+  float g = -(weight * (gscale ? gscale[0] : 1.f)) * (b * powf(fabsf(c) * 2.f, b - 1.f)) * 2.f * sg * hp;
+  dalpha[i] = accumulate ? dalpha[i] + g : g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Adam (torch/optim/adam.py _single_tensor_adam, no weight decay, no amsgrad)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float step_size, float beta1, float beta2, float eps,
+                                                   float bc2_sqrt) {
+  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  float gi = g[i];
+  float mi = m[i];
+  mi = mi + (1.f - beta1) * (gi - mi);         // exp_avg.lerp_(grad, 1-beta1)
+  float vi = v[i] * beta2 + (1.f - beta2) * (gi * gi);  // mul_(beta2).addcmul_(g, g, value=1-beta2)
+  m[i] = mi;
+  v[i] = vi;
+  float denom = sqrtf(vi) / bc2_sqrt + eps;
+  p[i] = p[i] - step_size * (mi / denom);      // addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+inline dim3 row_grid(int64_t rows, int64_t row_len) {
+  return dim3((unsigned)((row_len + TPB * EPT - 1) / (TPB * EPT)), (unsigned)rows, 1);
+}
+inline bool bad_rows(int64_t rows, int64_t row_len) { return rows <= 0 || row_len <= 0 || rows > 65535; }
+
+}  // namespace
+
+extern "C" {
+
+int nq_abi_version(void) { return 1; }
+
+const char* nq_error_string(int code) {
+  switch (code) {
+    case NQ_OK: return "ok";
+    case NQ_ERR_INVALID: return "invalid argument";
+    case NQ_ERR_UNSUPPORTED: return "unsupported shape";
+    case NQ_ERR_LAUNCH: return "HIP launch error";
+    default: return "unknown error";
+  }
+}
+
+int nq_scale_init_max(const float* x, int64_t rows, int64_t row_len, int n_levels, float* delta, float* zp,
+                      nq_stream_t stream) {
+  if (!x || !delta || !zp || rows <= 0 || row_len <= 0 || n_levels < 2) return NQ_ERR_INVALID;
+  hipLaunchKernelGGL(scale_init_kernel, dim3((unsigned)rows), dim3(TPB), 0, nq_s(stream), x, row_len, n_levels, delta,
+                     zp);
+  return nq_launch_status();
+}
+
+int nq_uaq_forward(const float* x, const float* delta, const float* zp, float* y, int64_t rows, int64_t row_len,
+                   int per_row, int n_levels, nq_stream_t stream) {
+  if (!x || !delta || !zp || !y || bad_rows(rows, row_len)) return NQ_ERR_INVALID;
+  hipLaunchKernelGGL(uaq_fwd_kernel, row_grid(rows, row_len), dim3(TPB), 0, nq_s(stream), x, delta, zp, y, row_len,
+                     per_row, (float)(n_levels - 1));
+  return nq_launch_status();
+}
+
+int nq_uaq_backward(const float* x, const float* gy, const float* delta, const float* zp, float* ddelta, int64_t rows,
+                    int64_t row_len, int per_row, int n_levels, nq_stream_t stream) {
+  if (!x || !gy || !delta || !zp || !ddelta || rows <= 0 || row_len <= 0) return NQ_ERR_INVALID;
+  // per_row=0 -> the whole tensor is one reduction row
+  int64_t r = per_row ? rows : 1, len = per_row ? row_len : rows * row_len;
+  hipLaunchKernelGGL(uaq_bwd_kernel, dim3((unsigned)r), dim3(TPB), 0, nq_s(stream), x, gy, delta, zp, ddelta, len,
+                     per_row, (float)(n_levels - 1));
+  return nq_launch_status();
+}
+
+int nq_adaround_init(const float* x, const float* delta_in, const float* zp_in, float* delta_out, float* zp_out,
+                     float* alpha, int64_t rows, int64_t row_len, int per_row, nq_stream_t stream) {
+  if (!x || !delta_in || !zp_in || !delta_out || !zp_out || !alpha || bad_rows(rows, row_len)) return NQ_ERR_INVALID;
+  int64_t ns = per_row ? rows : 1;
+  hipLaunchKernelGGL(adaround_scale_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, nq_s(stream), delta_in,
+                     zp_in, delta_out, zp_out, ns);
+  hipLaunchKernelGGL(adaround_alpha_init_kernel, row_grid(rows, row_len), dim3(TPB), 0, nq_s(stream), x, delta_out,
+                     alpha, row_len, per_row);
+  return nq_launch_status();
+}
+
+int nq_adaround_forward(const float* x, const float* alpha, const float* delta, const float* zp, float* y, float* xq,
+                        int64_t rows, int64_t row_len, int per_row, int n_levels, int soft, nq_stream_t stream) {
+  if (!x || !alpha || !delta || !zp || !y || bad_rows(rows, row_len)) return NQ_ERR_INVALID;
+  hipLaunchKernelGGL(adaround_fwd_kernel, row_grid(rows, row_len), dim3(TPB), 0, nq_s(stream), x, alpha, delta, zp, y,
+                     xq, row_len, per_row, (float)(n_levels - 1), soft);
+  return nq_launch_status();
+}
+
+int nq_adaround_backward(const float* x, const float* gy, const float* alpha, const float* delta, const float* zp,
+                         float* dalpha, int64_t rows, int64_t row_len, int per_row, int n_levels, float reg_weight,
+                         float reg_b, nq_stream_t stream) {
+  if (!x || !gy || !alpha || !delta || !zp || !dalpha || bad_rows(rows, row_len)) return NQ_ERR_INVALID;
+  hipLaunchKernelGGL(adaround_bwd_kernel, row_grid(rows, row_len), dim3(TPB), 0, nq_s(stream), x, gy, alpha, delta, zp,
+                     dalpha, row_len, per_row, (float)(n_levels - 1), reg_weight, reg_b);
+  return nq_launch_status();
+}
+
+int64_t nq_reduce_ws_floats(int64_t n) { return n <= 0 ? 1 : (n + RED_CHUNK - 1) / RED_CHUNK; }
+
+int nq_round_loss(const float* alpha, int64_t n, float b, float weight, float* ws, float* out, int accumulate,
+                  nq_stream_t stream) {
+  if (!alpha || !ws || !out || n <= 0) return NQ_ERR_INVALID;
+  int64_t parts = nq_reduce_ws_floats(n);
+  hipLaunchKernelGGL(round_loss_stage1, dim3((unsigned)parts), dim3(TPB), 0, nq_s(stream), alpha, n, b, ws);
+  hipLaunchKernelGGL(nq_sum_stage2, dim3(1), dim3(TPB), 0, nq_s(stream), ws, parts, weight, out, accumulate);
+  return nq_launch_status();
+}
+
+int nq_round_loss_backward(const float* alpha, int64_t n, float b, float weight, const float* gscale, float* dalpha,
+                           int accumulate, nq_stream_t stream) {
+  if (!alpha || !dalpha || n <= 0) return NQ_ERR_INVALID;
+  hipLaunchKernelGGL(round_loss_bwd_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, nq_s(stream), alpha, n,
+                     b, weight, gscale, dalpha, accumulate);
+  return nq_launch_status();
+}
+
+int nq_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float beta1, float beta2,
+                 float eps, float bc2_sqrt, nq_stream_t stream) {
+  if (!p || !g || !m || !v || n <= 0) return NQ_ERR_INVALID;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, nq_s(stream), p, g, m, v, n,
+                     step_size, beta1, beta2, eps, bc2_sqrt);
+  return nq_launch_status();
+}
+
+}  // extern "C"

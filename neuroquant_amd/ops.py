@@ -1,0 +1,381 @@
+"""Torch-facing wrappers of the libnqhip C ABI (include/nq_hip.h).
+
+PyTorch is plumbing here: device memory, the current HIP stream and the autograd tape.  All arithmetic on
+the hot path runs in the hand-written gfx950 kernels; there is NO CPU / eager fallback -- every op raises if
+its tensors are not fp32 HIP tensors or if libnqhip.so is missing.
+"""
+import ctypes
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+
+EPI_PLAIN, EPI_PS_GELU, EPI_TANH = L.EPI_PLAIN, L.EPI_PS_GELU, L.EPI_TANH
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name="tensor") -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"neuroquant_amd: {name} must live on the GPU (no CPU fallback exists)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"neuroquant_amd: {name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _rows(x: torch.Tensor, scale: torch.Tensor):
+    """(rows, row_len, per_row) of the quantiser kernels for tensor x and its delta/zp tensor."""
+    if scale.numel() > 1:
+        rows = x.shape[0]
+        if scale.numel() != rows:
+            raise RuntimeError("delta/zero_point must hold one value per output channel or a single value")
+        return rows, x.numel() // rows, 1
+    return 1, x.numel(), 0
+
+
+# ------------------------------------------------------------------------------------------ quantisers
+def scale_init_max(x: torch.Tensor, n_levels: int, channel_wise: bool):
+    """UniformAffineQuantizer.init_quantization_scale 'max' (reference quantizer.py:127-168)."""
+    x = _dev(x.detach(), "x")
+    if channel_wise:
+        if x.dim() == 4:
+            rows, shape = x.shape[0], (-1, 1, 1, 1)
+        elif x.dim() == 1:
+            rows, shape = 1, (-1,)
+        else:
+            raise ValueError
+    else:
+        rows, shape = 1, ()
+    delta = torch.empty(rows, device=x.device, dtype=torch.float32)
+    zp = torch.empty_like(delta)
+    L.check(L.lib().nq_scale_init_max(_p(x), rows, x.numel() // rows, n_levels, _p(delta), _p(zp), _stream()), "scale_init")
+    return delta.view(shape), zp.view(shape)
+
+
+def uaq_forward(x, delta, zp, n_levels, out=None):
+    x, delta, zp = _dev(x), _dev(delta), _dev(zp)
+    rows, rl, per_row = _rows(x, delta)
+    y = torch.empty_like(x) if out is None else out
+    L.check(L.lib().nq_uaq_forward(_p(x), _p(delta), _p(zp), _p(y), rows, rl, per_row, n_levels, _stream()), "uaq_forward")
+    return y
+
+
+def uaq_backward(x, gy, delta, zp, n_levels):
+    x, gy, delta, zp = _dev(x), _dev(gy), _dev(delta), _dev(zp)
+    rows, rl, per_row = _rows(x, delta)
+    dd = torch.empty_like(delta)
+    L.check(L.lib().nq_uaq_backward(_p(x), _p(gy), _p(delta), _p(zp), _p(dd), rows, rl, per_row, n_levels, _stream()),
+            "uaq_backward")
+    return dd
+
+
+def adaround_init(x, delta_uaq, zp_uaq):
+    """-> (delta, zp) after the fp16 round trip, alpha  (reference quantizer.py:264-265, 305-314)."""
+    x, d0, z0 = _dev(x.detach()), _dev(delta_uaq.detach()), _dev(zp_uaq.detach())
+    rows, rl, per_row = _rows(x, d0)
+    d, z, a = torch.empty_like(d0), torch.empty_like(z0), torch.empty_like(x)
+    L.check(L.lib().nq_adaround_init(_p(x), _p(d0), _p(z0), _p(d), _p(z), _p(a), rows, rl, per_row, _stream()),
+            "adaround_init")
+    return d, z, a
+
+
+def adaround_forward(x, alpha, delta, zp, n_levels, soft, want_xq=False, out=None):
+    x, alpha, delta, zp = _dev(x), _dev(alpha), _dev(delta), _dev(zp)
+    rows, rl, per_row = _rows(x, delta)
+    y = torch.empty_like(x) if out is None else out
+    xq = torch.empty_like(x) if want_xq else None
+    L.check(L.lib().nq_adaround_forward(_p(x), _p(alpha), _p(delta), _p(zp), _p(y), _p(xq), rows, rl, per_row, n_levels,
+                                        1 if soft else 0, _stream()), "adaround_forward")
+    return (y, xq) if want_xq else y
+
+
+def adaround_backward(x, gy, alpha, delta, zp, n_levels, reg_weight=0.0, reg_b=0.0, out=None):
+    x, gy, alpha, delta, zp = _dev(x), _dev(gy), _dev(alpha), _dev(delta), _dev(zp)
+    rows, rl, per_row = _rows(x, delta)
+    da = torch.empty_like(alpha) if out is None else out
+    L.check(L.lib().nq_adaround_backward(_p(x), _p(gy), _p(alpha), _p(delta), _p(zp), _p(da), rows, rl, per_row, n_levels,
+                                         float(reg_weight), float(reg_b), _stream()), "adaround_backward")
+    return da
+
+
+def round_loss(alpha, b, weight, out=None, accumulate=False):
+    alpha = _dev(alpha)
+    n = alpha.numel()
+    ws = torch.empty(L.lib().nq_reduce_ws_floats(n), device=alpha.device, dtype=torch.float32)
+    if out is None:
+        out = torch.zeros((), device=alpha.device, dtype=torch.float32)
+    L.check(L.lib().nq_round_loss(_p(alpha), n, float(b), float(weight), _p(ws), _p(out), 1 if accumulate else 0, _stream()),
+            "round_loss")
+    return out
+
+
+def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    """One torch.optim.Adam update of tensor p in place (step counts from 1)."""
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    L.check(L.lib().nq_adam_step(_p(p), _p(_dev(g)), _p(m), _p(v), p.numel(), lr / bc1, beta1, beta2, eps, bc2 ** 0.5,
+                                 _stream()), "adam_step")
+
+
+class FusedAdam:
+    """torch.optim.Adam(params, lr) with default betas/eps, one nq_adam_step launch per tensor."""
+
+    def __init__(self, params, lr):
+        self.params = [p for p in params]
+        self.lr = lr
+        self.t = 0
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self, grads=None):
+        self.t += 1
+        for i, p in enumerate(self.params):
+            g = p.grad if grads is None else grads[i]
+            if g is None:
+                continue
+            adam_step(p.data, g, self.m[i], self.v[i], self.lr, self.t)
+
+
+class _UAQFn(Function):
+    @staticmethod
+    def forward(ctx, x, delta, zp, n_levels):
+        ctx.save_for_backward(x, delta, zp)
+        ctx.n_levels = n_levels
+        return uaq_forward(x, delta, zp, n_levels)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, delta, zp = ctx.saved_tensors
+        # d/dx (straight-through) is never consumed on this path: the FP weight is not optimised
+        return None, uaq_backward(x, gy, delta, zp, ctx.n_levels).view_as(delta), None, None
+
+
+class _AdaRoundFn(Function):
+    @staticmethod
+    def forward(ctx, x, alpha, delta, zp, n_levels, soft):
+        y, xq = adaround_forward(x, alpha, delta, zp, n_levels, soft, want_xq=True)
+        ctx.save_for_backward(x, alpha, delta, zp)
+        ctx.n_levels, ctx.soft = n_levels, soft
+        ctx.mark_non_differentiable(xq)
+        return y, xq
+
+    @staticmethod
+    def backward(ctx, gy, _gxq):
+        x, alpha, delta, zp = ctx.saved_tensors
+        da = adaround_backward(x, gy, alpha, delta, zp, ctx.n_levels) if ctx.soft else None
+        return None, da, None, None, None, None
+
+
+class _RoundLossFn(Function):
+    @staticmethod
+    def forward(ctx, alpha, b, weight):
+        ctx.save_for_backward(alpha)
+        ctx.b, ctx.weight = float(b), float(weight)
+        return round_loss(alpha, b, weight)
+
+    @staticmethod
+    def backward(ctx, g):
+        (alpha,) = ctx.saved_tensors
+        da = torch.empty_like(alpha)
+        L.check(L.lib().nq_round_loss_backward(_p(alpha), alpha.numel(), ctx.b, ctx.weight, _p(_dev(g)), _p(da), 0, _stream()),
+                "round_loss_backward")
+        return da, None, None
+
+
+def uaq_fake_quant(x, delta, zp, n_levels):
+    return _UAQFn.apply(x, delta, zp, n_levels)
+
+
+def adaround_fake_quant(x, alpha, delta, zp, n_levels, soft):
+    return _AdaRoundFn.apply(x, alpha, delta, zp, n_levels, soft)
+
+
+def round_regulariser(alpha, b, weight):
+    return _RoundLossFn.apply(alpha, b, weight)
+
+
+# ------------------------------------------------------------------------------------------ Hadamard
+def next_pow2(n: int) -> int:
+    return 1 if n == 0 else 2 ** math.ceil(math.log2(n))
+
+
+def fwht_channels(w: torch.Tensor, n: int, n_out: int) -> torch.Tensor:
+    """WHT of length n along dim 1 of (C_out, C, KH, KW): input zero-padded from C to n, first n_out kept."""
+    w = _dev(w)
+    co, c, kh, kw = w.shape
+    y = torch.empty((co, n_out, kh, kw), device=w.device, dtype=torch.float32)
+    L.check(L.lib().nq_fwht(_p(w), _p(y), co, n, kh * kw, c, n_out, _stream()), "fwht")
+    return y
+
+
+class _HadamardFn(Function):
+    @staticmethod
+    def forward(ctx, w, n, n_out):
+        ctx.n, ctx.c_in = n, w.shape[1]
+        return fwht_channels(w, n, n_out)
+
+    @staticmethod
+    def backward(ctx, g):
+        return fwht_channels(g, ctx.n, ctx.c_in), None, None
+
+
+def hadamard_along_channel_weight(x: torch.Tensor, n_out=None) -> torch.Tensor:
+    """reference quant_layer.py:16-22 (differentiable; n_out folds the [:, :C] slice of :71 into the store)."""
+    n = next_pow2(x.shape[1])
+    if n != x.shape[1] and n_out is None:
+        raise ValueError("channel count must be a power of two (pad first, quant_layer.py:45-49)")
+    return _HadamardFn.apply(x, n, x.shape[1] if n_out is None else n_out)
+
+
+def hadamard_weight_of(w: torch.Tensor) -> torch.Tensor:
+    """zero-pad C_in to 2^k, then transform (reference quant_layer.py:45-49)."""
+    n = next_pow2(w.shape[1])
+    return fwht_channels(w.detach(), n, n)
+
+
+# ------------------------------------------------------------------------------------------ convolution
+def conv_operand_dims(cin, cout, k):
+    kr, ld = ctypes.c_int(0), ctypes.c_int(0)
+    L.check(L.lib().nq_conv_operand_dims(cin, cout, k, ctypes.byref(kr), ctypes.byref(ld)), "conv_operand_dims")
+    return kr.value, ld.value
+
+
+def weight_layouts(w, need_bwd):
+    """-> (wt_fwd, dims_fwd, wt_bwd | None, dims_bwd | None) GEMM operands of an OIHW weight."""
+    w = _dev(w)
+    cout, cin, k, _ = w.shape
+    kf, lf = conv_operand_dims(cin, cout, k)
+    wt = torch.empty(kf * lf, device=w.device, dtype=torch.float32)
+    wb, kb, lb = None, 0, 0
+    if need_bwd:
+        kb, lb = conv_operand_dims(cout, cin, k)
+        wb = torch.empty(kb * lb, device=w.device, dtype=torch.float32)
+    L.check(L.lib().nq_weight_layouts(_p(w), _p(wt), _p(wb), cout, cin, k, kf, lf, kb, lb, _stream()), "weight_layouts")
+    return wt, (kf, lf), wb, (kb, lb)
+
+
+def conv_forward_raw(x, wt, dims, bias, cout, k, epilogue, r):
+    B, cin, H, W = x.shape
+    z = None
+    if epilogue == EPI_PS_GELU:
+        y = torch.empty((B, cout // (r * r), H * r, W * r), device=x.device, dtype=torch.float32)
+        z = torch.empty_like(y)
+    else:
+        y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+    L.check(L.lib().nq_conv_forward(_p(x), _p(wt), _p(bias), _p(y), _p(z), B, cin, H, W, cout, k, dims[0], dims[1], r,
+                                    epilogue, _stream()), "conv_forward")
+    return y, z
+
+
+def conv_wgrad_raw(x, dy, cout, k, want_db):
+    B, cin, H, W = x.shape
+    ws = torch.empty(L.lib().nq_conv_wgrad_ws_floats(B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
+    dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32)
+    db = torch.empty(cout, device=x.device, dtype=torch.float32) if want_db else None
+    L.check(L.lib().nq_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k, _stream()), "conv_wgrad")
+    return dw, db
+
+
+class _ConvFn(Function):
+    """stride-1 'same' conv (+bias) fused with PixelShuffle+GELU or tanh*0.5+0.5 (reference quant_layer.py:80,
+    quant_block.py:31-35, models/_layers.py:10-36)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, epilogue, r):
+        x, w = _dev(x, "x"), _dev(w, "weight")
+        b = _dev(b, "bias") if b is not None else None
+        cout, cin, k, k2 = w.shape
+        if k != k2 or x.shape[1] != cin:
+            raise ValueError(f"conv shape mismatch: x {tuple(x.shape)} w {tuple(w.shape)}")
+        need_dx = ctx.needs_input_grad[0]
+        wt, dims, wb, dims_b = weight_layouts(w, need_dx)
+        y, z = conv_forward_raw(x, wt, dims, b, cout, k, epilogue, r)
+        ctx.save_for_backward(x, wb, z if epilogue == EPI_PS_GELU else (y if epilogue == EPI_TANH else None))
+        ctx.meta = (cout, cin, k, epilogue, r, dims_b, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wb, aux = ctx.saved_tensors
+        cout, cin, k, epilogue, r, dims_b, has_b = ctx.meta
+        B, _, H, W = x.shape
+        gy = _dev(gy, "grad")
+        if epilogue == EPI_PS_GELU:
+            dconv = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+            L.check(L.lib().nq_ps_gelu_backward(_p(gy), _p(aux), _p(dconv), B, cout // (r * r), H, W, r, _stream()),
+                    "ps_gelu_backward")
+        elif epilogue == EPI_TANH:
+            dconv = torch.empty_like(gy)
+            L.check(L.lib().nq_tanh_out_backward(_p(gy), _p(aux), _p(dconv), gy.numel(), _stream()), "tanh_backward")
+        else:
+            dconv = gy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx, _ = conv_forward_raw(dconv, wb, dims_b, None, cin, k, EPI_PLAIN, 1)
+        if ctx.needs_input_grad[1] or (has_b and ctx.needs_input_grad[2]):
+            dw, db = conv_wgrad_raw(x, dconv, cout, k, has_b)
+        return dx, dw, db, None, None
+
+
+def conv2d_fused(x, w, b, epilogue=EPI_PLAIN, r=1):
+    return _ConvFn.apply(x, w, b, epilogue, r)
+
+
+# ------------------------------------------------------------------------------------------ loss / metrics / frames
+class _L2LossFn(Function):
+    """lp_loss(pred, tgt, p=2): sum over channels, mean over batch*H*W (reference quantizer.py:66-71)."""
+
+    @staticmethod
+    def forward(ctx, pred, tgt):
+        pred, tgt = _dev(pred, "pred"), _dev(tgt, "tgt")
+        n = pred.numel()
+        mean_count = n // pred.shape[1]
+        loss = torch.empty((), device=pred.device, dtype=torch.float32)
+        dpred = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+        ws = torch.empty(L.lib().nq_reduce_ws_floats(n), device=pred.device, dtype=torch.float32)
+        L.check(L.lib().nq_l2_loss(_p(pred), _p(tgt), _p(loss), _p(dpred), _p(ws), n, mean_count, 1.0, _stream()), "l2_loss")
+        ctx.save_for_backward(dpred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g, None
+
+
+def l2_loss(pred, tgt):
+    return _L2LossFn.apply(pred, tgt)
+
+
+def frame_psnr(out, gt):
+    """per-frame PSNR (reference utils.py:148-151): -10*log10(mean((out-gt)^2) + 1e-9)."""
+    out, gt = _dev(out.detach()), _dev(gt.detach())
+    frames = out.shape[0]
+    flen = out.numel() // frames
+    sse = torch.empty(frames, device=out.device, dtype=torch.float32)
+    L.check(L.lib().nq_frame_sse(_p(out), _p(gt), _p(sse), frames, flen, _stream()), "frame_sse")
+    return -10 * torch.log10(sse / flen + 1e-9)
+
+
+def gather_frames_u8(frames_u8: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    """float frames[idx] / 255 from a GPU-resident uint8 cache (reference videosets/datasets.py:19-24)."""
+    if not frames_u8.is_cuda or frames_u8.dtype != torch.uint8 or not frames_u8.is_contiguous():
+        raise RuntimeError("frame cache must be a contiguous uint8 GPU tensor")
+    idx = idx.to(device=frames_u8.device, dtype=torch.int64).contiguous()
+    n = idx.numel()
+    flen = frames_u8[0].numel()
+    out = torch.empty((n,) + tuple(frames_u8.shape[1:]), device=frames_u8.device, dtype=torch.float32)
+    L.check(L.lib().nq_gather_frames_u8(_p(frames_u8), _p(idx), _p(out), n, flen, _stream()), "gather_frames")
+    return out

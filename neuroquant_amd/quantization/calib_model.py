@@ -1,0 +1,223 @@
+"""Network-wise calibration (reference quantization/calib_model.py): learn the per-channel scales, then the
+AdaRound rounding variables, against the reconstruction loss of the WHOLE decoder.
+
+`model_reconstruction` keeps the reference's signature and in-place semantics but runs each iteration as an
+explicit schedule on HIP kernels:
+
+    fake-quant (+Hadamard) of all layers          nq_uaq_forward / nq_adaround_forward / nq_fwht
+    decoder forward + backward                    nq_conv_forward / nq_conv_wgrad / nq_ps_gelu_backward ...
+    reconstruction loss + its gradient            nq_l2_loss
+    d(delta) or d(alpha) + regulariser gradient   nq_uaq_backward / nq_adaround_backward (fused)
+    Adam                                          nq_adam_step
+
+Autograd only spans the convolution stack; the parameter side is explicit, so no per-layer graph nodes, no
+host synchronisation per iteration (the reference's decode sync and 500-step float() logging are the only
+syncs it had; the log sync is kept, the decode sync is not).
+"""
+import logging
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .data_utils import LinearTempDecay
+from .quant_layer import QuantModule
+from .quant_model import QuantModel
+from .quantizer import AdaRoundQuantizer, lp_loss
+
+
+def _quant_modules(module: nn.Module, out=None):
+    """QuantModules in the order of the reference's recursion (children order, '*encoder*' skipped)."""
+    out = [] if out is None else out
+    for name, child in module.named_children():
+        if 'encoder' in name:
+            continue
+        if isinstance(child, QuantModule):
+            out.append(child)
+        else:
+            _quant_modules(child, out)
+    return out
+
+
+class LossFunction:
+    """rec loss + rounding regulariser with a linear temperature schedule (reference calib_model.py:16-89).
+    Generic autograd form for callers that drive their own loop; `model_reconstruction` uses the fused kernels."""
+
+    def __init__(self, model: nn.Module, round_loss: str = 'relaxation', weight: float = 1., rec_loss: str = 'mse',
+                 max_count: int = 2000, b_range: tuple = (10, 2), decay_start: float = 0.0, warmup: float = 0.0,
+                 p: float = 2.):
+        self.model = model
+        self.round = round_loss
+        self.weight = weight
+        self.rec = rec_loss
+        self.loss_start = max_count * warmup
+        self.p = p
+        self.temp_decay = LinearTempDecay(max_count, rel_start_decay=warmup + (1 - warmup) * decay_start,
+                                          start_b=b_range[0], end_b=b_range[1])
+        self.count = 0
+        self.round_loss = 0
+
+    def collect_round_loss(self, module, b):
+        for m in _quant_modules(module):
+            self.round_loss = self.round_loss + ops.round_regulariser(m.weight_quantizer.alpha, b, self.weight)
+
+    def __call__(self, pred, tgt, grad=None):
+        self.count += 1
+        if self.rec != 'mse':
+            raise NotImplementedError(f'rec_loss {self.rec!r}: the drivers hard-code opt_mode="mse"')
+        rec_loss = lp_loss(pred, tgt, p=self.p)
+        b = self.temp_decay(self.count)
+        if self.count < self.loss_start or self.round == 'none':
+            b = self.round_loss = 0
+        elif self.round == 'relaxation':
+            self.round_loss = 0
+            self.collect_round_loss(self.model, b)
+        else:
+            raise NotImplementedError
+        total_loss = self.round_loss + rec_loss
+        if self.count % 500 == 0:
+            logging.info('Total loss:\t{:.4f} (rec:{:.4f}, round:{:.4f})\tb={:.2f}\tcount={}'.format(
+                float(total_loss), float(rec_loss), float(self.round_loss), b, self.count))
+        return total_loss
+
+
+class _Layer:
+    """Per-QuantModule view used by the explicit schedule."""
+
+    def __init__(self, m: QuantModule, hadamard: bool):
+        self.m = m
+        self.hadamard = hadamard
+        self.src = m.hadamard_weight if hadamard else m.weight.data
+        self.n = self.src.shape[1]           # transform length (C_pad) when hadamard
+        self.c_in = m.weight.shape[1]
+        self.bias = m.bias.data
+        self.W = self.b = None
+
+    def forward_uaq(self):
+        wq, bq = self.m.weight_quantizer, self.m.bias_quantizer
+        Wq = ops.uaq_forward(self.src, wq.delta.data, wq.zero_point, wq.n_levels)
+        self._finish(Wq, ops.uaq_forward(self.bias, bq.delta.data, bq.zero_point, bq.n_levels))
+
+    def forward_ada(self):
+        wq, bq = self.m.weight_quantizer, self.m.bias_quantizer
+        Wq = ops.adaround_forward(self.src, wq.alpha.data, wq.delta.data, wq.zero_point, wq.n_levels, wq.soft_targets)
+        self._finish(Wq, ops.adaround_forward(self.bias, bq.alpha.data, bq.delta.data, bq.zero_point, bq.n_levels,
+                                              bq.soft_targets))
+
+    def _finish(self, Wq, b):
+        self.W = (ops.fwht_channels(Wq, self.n, self.c_in) if self.hadamard else Wq).requires_grad_(True)
+        self.b = b.requires_grad_(True)
+        self.m._wb_override = (self.W, self.b)
+
+    def grads(self):
+        gW = self.W.grad
+        if self.hadamard:
+            gW = ops.fwht_channels(gW, self.n, self.n)   # H on the zero-padded gradient
+        return gW, self.b.grad
+
+    def release(self):
+        self.m._wb_override = None
+        self.W = self.b = None
+
+
+def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: str = 'hnerv', batch_size: int = 8,
+                         iters: int = 20000, weight: float = 0.01, opt_mode: str = 'mse', hadamard: bool = True,
+                         b_range: tuple = (20, 2), warmup: float = 0.0, p: float = 2.0, lr: float = 0.0015,
+                         recorder: list = None, max_steps: int = None):
+    """Network-wise calibration, in place (reference calib_model.py:92-240).
+
+    gt: any sized iterable of dict batches {'img' (B,3,H,W), 'idx' (B,), 'norm_idx'}; cali_data[idx] feeds the
+    decoder.  recorder (optional list) receives (total, round, b, count) per iteration -- this forces one host
+    sync per iteration and is meant for parity tests.  max_steps truncates the run (bench sampling).
+    """
+    if arch not in ('hnerv', 'nerv'):
+        raise ValueError
+    if opt_mode != 'mse' or p != 2.0:
+        raise NotImplementedError('only opt_mode="mse", p=2 is on the calibration path')
+    model.set_quant_state(True)
+    device = next(model.parameters()).device
+    layers = [_Layer(m, hadamard) for m in _quant_modules(model)]
+    for L in layers:  # scales are initialised lazily at the first quantiser call (quantizer.py:112-115)
+        if not L.m.weight_quantizer.inited:
+            L.m.weight_quantizer(L.src)
+        if not L.m.bias_quantizer.inited:
+            L.m.bias_quantizer(L.bias)
+    done = 0
+
+    def run(epochs, params, opt_lr, max_count, ada):
+        nonlocal done
+        opt = ops.FusedAdam(params, lr=opt_lr)
+        loss_start = max_count * warmup
+        temp = LinearTempDecay(max_count, rel_start_decay=warmup, start_b=b_range[0], end_b=b_range[1])
+        count = 0
+        for _ in range(epochs):
+            model.train()
+            for sample in gt:
+                if max_steps is not None and done >= max_steps:
+                    return
+                img = sample['img'].to(device, non_blocking=True)
+                inputs = cali_data[sample['idx'].to(device, non_blocking=True)]
+                count += 1
+                b = temp(count)
+                reg_on = ada and not (count < loss_start)
+                if not reg_on:
+                    b = 0
+                for L in layers:
+                    L.forward_ada() if ada else L.forward_uaq()
+                img_out, _, _ = model(inputs)
+                rec = ops.l2_loss(img_out, img)
+                rec.backward()
+                grads = []
+                for L in layers:
+                    gW, gb = L.grads()
+                    wq, bq = L.m.weight_quantizer, L.m.bias_quantizer
+                    if ada:
+                        grads.append(ops.adaround_backward(L.src, gW, wq.alpha.data, wq.delta.data, wq.zero_point,
+                                                           wq.n_levels, weight if reg_on else 0.0, b))
+                        grads.append(ops.adaround_backward(L.bias, gb, bq.alpha.data, bq.delta.data, bq.zero_point,
+                                                           bq.n_levels))
+                    else:
+                        grads.append(ops.uaq_backward(L.src, gW, wq.delta.data, wq.zero_point, wq.n_levels))
+                        grads.append(ops.uaq_backward(L.bias, gb, bq.delta.data, bq.zero_point, bq.n_levels))
+                want_log = recorder is not None or count % 500 == 0
+                if want_log:
+                    rl = torch.zeros((), device=device)
+                    if reg_on:
+                        for L in layers:
+                            ops.round_loss(L.m.weight_quantizer.alpha.data, b, weight, out=rl, accumulate=True)
+                    total, rl_f = float(rec) + float(rl), float(rl)
+                    if recorder is not None:
+                        recorder.append((total, rl_f, float(b), count))
+                    if count % 500 == 0:
+                        logging.info('Total loss:\t{:.4f} (rec:{:.4f}, round:{:.4f})\tb={:.2f}\tcount={}'.format(
+                            total, float(rec), rl_f, b, count))
+                opt.step(grads)
+                for L in layers:
+                    L.release()
+                done += 1
+
+    # ---- phase 1: scales (calib_model.py:119-165; lr and max_count are hard-coded there) ----
+    params = []
+    for L in layers:
+        params += [L.m.weight_quantizer.delta, L.m.bias_quantizer.delta]
+    epochs1 = int(0.05 * iters / len(gt))
+    run(epochs1, params, 0.001, 2100, ada=False)
+    torch.cuda.empty_cache()
+
+    # ---- phase 2: rounding variables (calib_model.py:170-226) ----
+    params = []
+    for L in layers:
+        m = L.m
+        m.weight_quantizer = AdaRoundQuantizer(uaq=m.weight_quantizer, round_mode='learned_hard_sigmoid',
+                                               weight_tensor=(m.hadamard_weight if hadamard else m.org_weight).data)
+        m.bias_quantizer = AdaRoundQuantizer(uaq=m.bias_quantizer, round_mode='learned_hard_sigmoid',
+                                             weight_tensor=m.bias.data)
+        m.weight_quantizer.soft_targets = True
+        m.bias_quantizer.soft_targets = True
+        params += [m.weight_quantizer.alpha, m.bias_quantizer.alpha]
+    run(int(iters / len(gt)) - epochs1, params, lr, iters, ada=True)
+    torch.cuda.empty_cache()
+
+    # ---- finish: weights go hard; the bias quantisers stay soft, as in the reference (calib_model.py:231-240) ----
+    for L in layers:
+        L.m.weight_quantizer.soft_targets = False

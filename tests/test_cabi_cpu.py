@@ -1,0 +1,111 @@
+"""CPU-side checks of the boundary: libnqhip.so loads, exports every symbol include/nq_hip.h declares, rejects bad
+arguments before touching the device, and the host-side mirror of the reference API behaves like the reference
+(known answers from the reference's own logs)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, HNERV_3M, NERV_3M, TINY_HNERV, BITS
+
+
+def test_header_symbols_exported():
+    from neuroquant_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "nq_hip.h")).read()
+    declared = set(re.findall(r"\b(nq_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in nq_hip.h but not exported"
+    assert declared == set(_lib.EXPORTS)
+    assert lib.nq_abi_version() == 1
+    assert lib.nq_error_string(-1) == b"invalid argument"
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    from neuroquant_amd import _lib
+    lib = _lib.lib()
+    n = None
+    assert lib.nq_uaq_forward(n, n, n, n, 4, 4, 1, 16, n) == -1
+    assert lib.nq_fwht(ctypes.c_void_p(16), ctypes.c_void_p(32), 1, 12, 1, 12, 12, n) == -1      # not a power of two
+    assert lib.nq_fwht(ctypes.c_void_p(16), ctypes.c_void_p(32), 1, 2048, 1, 8, 8, n) == -2      # too long
+    assert lib.nq_conv_forward(ctypes.c_void_p(16), ctypes.c_void_p(16), n, ctypes.c_void_p(16), n, 1, 4, 8, 8, 4, 7, 196,
+                               16, 1, 0, n) == -2                                             # k=7 not built
+    kr, ld = ctypes.c_int(), ctypes.c_int()
+    assert lib.nq_conv_operand_dims(44, 148, 5, ctypes.byref(kr), ctypes.byref(ld)) == 0
+    assert kr.value == 44 * 25 and ld.value == 160
+    assert lib.nq_conv_operand_dims(53, 176, 5, ctypes.byref(kr), ctypes.byref(ld)) == 0
+    assert kr.value == 56 * 25 and ld.value == 176
+    assert lib.nq_conv_wgrad_ws_floats(2, 44, 320, 640, 148, 5) > 0
+    assert lib.nq_reduce_ws_floats(4096 * 3 + 1) == 4
+
+
+def test_ops_refuse_cpu_tensors():
+    from neuroquant_amd import ops
+    with pytest.raises(RuntimeError):
+        ops.uaq_forward(torch.zeros(2, 2), torch.ones(1), torch.zeros(1), 4)
+    with pytest.raises(RuntimeError):
+        ops.l2_loss(torch.zeros(1, 3, 2, 2), torch.zeros(1, 3, 2, 2))
+
+
+@pytest.mark.parametrize("arch,cfg,bits,want", [
+    ("hnerv", HNERV_3M, [6, 5, 4, 5, 5, 6, 6], 4.79399210722922),    # results/...052303.log:233
+    ("hnerv", HNERV_3M, [2, 3, 4, 6, 4, 4, 2], 4.956511535893288),   # results/...132138.log:233
+    ("nerv", NERV_3M, [6, 5, 4, 5, 5, 6, 6], 4.946213722986429),     # results/...080342.log:143
+])
+def test_average_bitwidth_known_answers(arch, cfg, bits, want):
+    from neuroquant_amd.models import HNeRV, NeRV
+    from neuroquant_amd.quantization import QuantModel, QuantModule, QuantNeRVBlock
+    model = (HNeRV if arch == "hnerv" else NeRV)(cfg)
+    dec = sum(p.numel() for p in model.decoder.parameters()) + sum(p.numel() for p in model.head_layer.parameters())
+    qnn = QuantModel(model, hadamard=False, weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
+    assert qnn.set_bitwidth(bits) == want
+    mods = qnn.quant_modules()
+    assert len(mods) == 7 and isinstance(qnn.model.decoder[1], QuantNeRVBlock)
+    assert isinstance(qnn.model.decoder[0], QuantModule) and isinstance(qnn.model.head_layer, QuantModule)
+    assert sum(m.weight.numel() + m.bias.numel() for m in mods) == dec
+    if arch == "hnerv":
+        assert not any(isinstance(m, QuantModule) for m in qnn.model.encoder.modules())   # encoder left alone
+        assert dec == 2646219                                                              # SURVEY §8 layer table
+    else:
+        assert dec == 3078499
+
+
+def test_bitwidth_bounds_and_state_toggles():
+    from neuroquant_amd.models import HNeRV
+    from neuroquant_amd.quantization import QuantModel, UniformAffineQuantizer
+    with pytest.raises(AssertionError):
+        UniformAffineQuantizer(n_bits=9)
+    q = UniformAffineQuantizer(n_bits=4)
+    with pytest.raises(AssertionError):
+        q.bitwidth_refactor(1)
+    qnn = QuantModel(HNeRV(TINY_HNERV), hadamard=False, weight_quant_params=dict(n_bits=8, channel_wise=True))
+    qnn.set_quant_state(True)
+    assert all(m.use_weight_quant for m in qnn.quant_modules())
+    qnn.set_quant_state(False)
+    assert not any(m.use_weight_quant for m in qnn.quant_modules())
+    qnn.set_bitwidth(BITS, init=False)
+    assert [m.weight_quantizer.n_bits for m in qnn.quant_modules()] == BITS
+    assert [m.bias_quantizer.n_levels for m in qnn.quant_modules()] == [2 ** b for b in BITS]
+
+
+def test_state_dict_keys_match_reference_checkpoints(golden):
+    from conftest import state_dict_from_npz
+    from neuroquant_amd.models import HNeRV
+    sd = state_dict_from_npz(golden("traj_hnerv.npz"), "sd:")
+    model = HNeRV(TINY_HNERV)
+    assert set(model.state_dict().keys()) == set(sd.keys())
+    model.load_state_dict(sd, strict=True)
+
+
+def test_temperature_schedule_matches_golden():
+    import json
+    from neuroquant_amd.quantization import LinearTempDecay
+    tab = json.load(open(os.path.join(ROOT, "tests", "golden", "tempdecay.json")))
+    for key, rows in tab.items():
+        t_max, rel = key.split("_")
+        sched = LinearTempDecay(int(t_max), rel_start_decay=float(rel), start_b=20, end_b=2)
+        for t, want in rows:
+            assert sched(t) == want
