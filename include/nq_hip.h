@@ -112,12 +112,15 @@ int nq_conv_operand_dims(int Cin, int Cout, int k, int* krows, int* ld);
  *            NQ_EPI_PS_GELU   : PixelShuffle(r) + exact-erf GELU (quant_block.py:31-35, _layers.py:20-36):
  *                               z (B,Cout/r^2,H*r,W*r) = shuffled pre-activation, y = gelu(z)
  *            NQ_EPI_TANH      : y = tanh(conv+bias)*0.5+0.5 (OutImg, _layers.py:10-16)
- * The data gradient of a convolution is the same call with wt = wt_bwd and Cin/Cout swapped. */
+ * The data gradient of a convolution is the same call with wt = wt_bwd and Cin/Cout swapped.
+ * ws: scratch of >= nq_conv_forward_ws_floats(...) floats (may be NULL when that is 0): layers with few pixel
+ * tiles split their K loop across workgroups; the partial sums are added in fixed order (deterministic). */
 #define NQ_EPI_PLAIN 0
 #define NQ_EPI_PS_GELU 1
 #define NQ_EPI_TANH 2
-int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y, float* z, int B, int Cin, int H, int W,
-                    int Cout, int k, int krows, int ld, int r, int epilogue, nq_stream_t stream);
+int64_t nq_conv_forward_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
+int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y, float* z, float* ws, int B, int Cin, int H,
+                    int W, int Cout, int k, int krows, int ld, int r, int epilogue, nq_stream_t stream);
 
 /* Weight + bias gradient of the same convolution: dw (Cout,Cin,k,k), db (Cout) (db may be NULL),
  * from x (B,Cin,H,W) and dy (B,Cout,H,W).  ws: scratch of >= nq_conv_wgrad_ws_floats(...) floats.

@@ -4,11 +4,12 @@
 
 extern "C" {
 int nq_conv_igemm_k1(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int,
-                     hipStream_t);
+                     int, float*, hipStream_t);
 int nq_conv_igemm_k3(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int,
-                     hipStream_t);
+                     int, float*, hipStream_t);
 int nq_conv_igemm_k5(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int,
-                     hipStream_t);
+                     int, float*, hipStream_t);
+int nq_conv_splitk_finish(const float*, const float*, float*, float*, int, int, int, int, int, int, int, hipStream_t);
 int nq_conv_wgrad_k1(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
                      hipStream_t);
 int nq_conv_wgrad_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
@@ -35,6 +36,19 @@ inline int pick_mi_fwd(int Cout) {
     }
   }
   return best;
+}
+
+// split-K factor of the implicit-GEMM kernel: layers with few pixel tiles (dec0..dec3 and their data gradients)
+// would otherwise occupy a handful of the 256 CUs with a very long K loop
+inline int pick_nsplit(int B, int Cin, int H, int W, int Cout, int k) {
+  const int mi = pick_mi_fwd(Cout);
+  const int64_t base = (int64_t)((W + 31) / 32) * ((H + 3) / 4) * ((Cout + 16 * mi - 1) / (16 * mi)) * B;
+  if (base >= 384) return 1;
+  const int ncg = (Cin + ci_per_slice(k) - 1) / ci_per_slice(k);
+  int ns = (int)((512 + base - 1) / base);
+  if (ns > ncg) ns = ncg;
+  if (ns > 32) ns = 32;
+  return ns < 1 ? 1 : ns;
 }
 
 inline int wgrad_ni(int mi, int k) { return k == 1 ? 2 : (mi <= 3 ? 6 : (mi <= 6 ? 4 : 3)); }
@@ -151,8 +165,14 @@ int nq_weight_layouts(const float* w, float* wt_fwd, float* wt_bwd, int Cout, in
   return nq_launch_status();
 }
 
-int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y, float* z, int B, int Cin, int H, int W,
-                    int Cout, int k, int krows, int ld, int r, int epilogue, nq_stream_t stream) {
+int64_t nq_conv_forward_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
+  if (!ks_ok(k) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  int ns = pick_nsplit(B, Cin, H, W, Cout, k);
+  return ns > 1 ? (int64_t)ns * B * Cout * H * W : 0;
+}
+
+int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y, float* z, float* ws, int B, int Cin, int H,
+                    int W, int Cout, int k, int krows, int ld, int r, int epilogue, nq_stream_t stream) {
   if (!x || !wt || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
   if (!ks_ok(k)) return NQ_ERR_UNSUPPORTED;
   if (epilogue == NQ_EPI_PS_GELU && (!z || r <= 0 || Cout % (r * r) != 0)) return NQ_ERR_INVALID;
@@ -162,12 +182,18 @@ int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y
   if (krows < need_rows || ld < need_ld || (ld & 3)) return NQ_ERR_INVALID;
   if (B > 65535) return NQ_ERR_UNSUPPORTED;
   const int mi = pick_mi_fwd(Cout);
+  const int ns = pick_nsplit(B, Cin, H, W, Cout, k);
+  if (ns > 1 && !ws) return NQ_ERR_INVALID;
+  if ((int64_t)B * ns > 65535) return NQ_ERR_UNSUPPORTED;
   hipStream_t st = nq_s(stream);
+  int rc;
   switch (k) {
-    case 1: return nq_conv_igemm_k1(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, st);
-    case 3: return nq_conv_igemm_k3(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, st);
-    default: return nq_conv_igemm_k5(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, st);
+    case 1: rc = nq_conv_igemm_k1(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, ns, ws, st); break;
+    case 3: rc = nq_conv_igemm_k3(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, ns, ws, st); break;
+    default: rc = nq_conv_igemm_k5(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, ns, ws, st); break;
   }
+  if (rc != NQ_OK || ns == 1) return rc;
+  return nq_conv_splitk_finish(ws, bias, y, z, B, H, W, Cout, r, epilogue, ns, st);
 }
 
 int64_t nq_conv_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {

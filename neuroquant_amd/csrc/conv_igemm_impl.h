@@ -19,6 +19,8 @@
 // service cycle hit disjoint bank halves.
 //
 // Roofline: MFMA-bound (fp32 matrix peak 157.3 TFLOP/s); algorithmic flops = 2*Cout*Cin*KS^2*H*W*B.
+#include <type_traits>
+
 #include "nq_common.h"
 
 #ifndef NQ_KS
@@ -35,7 +37,8 @@ struct ConvArgs {
   const float* bias;
   float* y;
   float* z;
-  int B, Cin, H, W, Cout, ld, r, epi, tiles_x, ncg;
+  int B, Cin, H, W, Cout, ld, r, epi, tiles_x, ncg, nsplit;
+  float* slab;  // [nsplit][B][Cout][H][W] partial sums when nsplit > 1
 };
 
 constexpr int KS = NQ_KS;
@@ -56,10 +59,19 @@ constexpr int PATCH_FLOATS = CI * PS;
 constexpr int PE = CI * PH * PW;               // patch elements to stage
 constexpr int PPT = (PE + 255) / 256;          // per thread
 
+// compile-time loop: f(integral_constant<int, I>) for I in [I0, N)
+template <int I0, int N, class F>
+__device__ __forceinline__ void igemm_steps(F&& f) {
+  if constexpr (I0 < N) {
+    f(std::integral_constant<int, I0>{});
+    igemm_steps<I0 + 1, N>(f);
+  }
+}
+
 __device__ __forceinline__ float gelu_exact(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 template <int MI>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_igemm_kernel(ConvArgs a) {
   constexpr int MT = 16 * MI;
   // (CIQ*KS*LDW) % 32 == 16 and LDW % 4 == 0
   constexpr int LDW = [] {
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
   const int x0 = tile_x * TW, y0 = tile_y * TH;
   const int co0 = blockIdx.y * MT;
-  const int b = blockIdx.z;
+  const int b = blockIdx.z / a.nsplit, split = blockIdx.z - b * a.nsplit;
   const int H = a.H, W = a.W, Cin = a.Cin;
   const float* __restrict__ xb = a.x + (int64_t)b * Cin * H * W;
   const float* __restrict__ wt = a.wt + co0;
@@ -88,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
 
   // ---- staging helpers ------------------------------------------------------------------------
   float pv[PPT];
-  float4 wv[WPT];
+  f32x4 wv[WPT];
   // per-thread patch element coordinates are slice-invariant: precompute offsets (or -1 when outside the image)
   int poff[PPT];   // offset inside one input plane, -1 = zero fill
   int pci[PPT];    // channel inside the group
@@ -104,40 +116,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     pci[i] = ci;
     plds[i] = (e < PE) ? ci * PS + r * PW + c : -1;
   }
-  auto load_patch = [&](int cg) {
-#pragma unroll
-    for (int i = 0; i < PPT; ++i) {
-      int cig = cg * CI + pci[i];
-      pv[i] = (poff[i] >= 0 && cig < Cin) ? xb[(int64_t)cig * H * W + poff[i]] : 0.f;
-    }
-  };
-  auto store_patch = [&](float* dst) {
-#pragma unroll
-    for (int i = 0; i < PPT; ++i)
-      if (plds[i] >= 0) dst[plds[i]] = pv[i];
-  };
-  auto load_w = [&](int cg, int kh) {
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      int f = tid + i * 256;
-      if (f < WF4) {
-        int row = f / (MT / 4), c4 = f - row * (MT / 4);
-        int ci = row / KS, kw = row - ci * KS;
-        int grow = ((cg * CI + ci) * KS + kh) * KS + kw;
-        wv[i] = *reinterpret_cast<const float4*>(wt + (int64_t)grow * ld + c4 * 4);
-      }
-    }
-  };
-  auto store_w = [&](float* dst) {
-#pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      int f = tid + i * 256;
-      if (f < WF4) {
-        int row = f / (MT / 4), c4 = f - row * (MT / 4);
-        *reinterpret_cast<float4*>(dst + row * LDW + c4 * 4) = wv[i];
-      }
-    }
-  };
+#define NQ_LOAD_PATCH(CG)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < PPT; ++i) {                                               \
+    int cig = (CG) * CI + pci[i];                                                                 \
+    pv[i] = (poff[i] >= 0 && cig < Cin) ? xb[(int64_t)cig * H * W + poff[i]] : 0.f;               \
+  }
+#define NQ_STORE_PATCH(DST)                                                                       \
+  _Pragma("unroll") for (int i = 0; i < PPT; ++i) {                                               \
+    if (plds[i] >= 0) (DST)[plds[i]] = pv[i];                                                     \
+  }
+#define NQ_LOAD_W(CG, KH)                                                                         \
+  _Pragma("unroll") for (int i = 0; i < WPT; ++i) {                                               \
+    int f = tid + i * 256;                                                                        \
+    if (i + 1 < WPT || f < WF4) {                                                                 \
+      int row = f / (MT / 4), c4 = f - row * (MT / 4);                                            \
+      int ci = row / KS, kw = row - ci * KS;                                                      \
+      int grow = (((CG) * CI + ci) * KS + (KH)) * KS + kw;                                        \
+      wv[i] = *reinterpret_cast<const f32x4*>(wt + (int64_t)grow * ld + c4 * 4);                 \
+    }                                                                                             \
+  }
+#define NQ_STORE_W(DST)                                                                           \
+  _Pragma("unroll") for (int i = 0; i < WPT; ++i) {                                               \
+    int f = tid + i * 256;                                                                        \
+    if (i + 1 < WPT || f < WF4) {                                                                 \
+      int row = f / (MT / 4), c4 = f - row * (MT / 4);                                            \
+      *reinterpret_cast<f32x4*>((DST) + row * LDW + c4 * 4) = wv[i];                             \
+    }                                                                                             \
+  }
 
   f32x4 acc[MI][2];
 #pragma unroll
@@ -150,14 +155,17 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int b_base = (kq * CIQ) * PS + wave * PW + l16;
 
   // ---- prologue -------------------------------------------------------------------------------
-  const int nslices = a.ncg * KS;
-  load_patch(0);
-  load_w(0, 0);
-  store_patch(patch0);
-  store_w(wl0);
+  // split-K: this workgroup covers channel groups [cg_lo, cg_hi)
+  const int cg_lo = (int)(((int64_t)a.ncg * split) / a.nsplit);
+  const int cg_hi = (int)(((int64_t)a.ncg * (split + 1)) / a.nsplit);
+  const int nslices = (cg_hi - cg_lo) * KS;
+  NQ_LOAD_PATCH(cg_lo)
+  NQ_LOAD_W(cg_lo, 0)
+  NQ_STORE_PATCH(patch0)
+  NQ_STORE_W(wl0)
   __syncthreads();
 
-  int cg = 0, kh = 0;
+  int cg = cg_lo, kh = 0;
   for (int s = 0; s < nslices; ++s) {
     int ncg_ = cg, nkh = kh + 1;
     if (nkh == KS) {
@@ -166,29 +174,59 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
     }
     const bool more = (s + 1 < nslices);
     const bool new_patch = more && (nkh == 0);
-    if (more) load_w(ncg_, nkh);
-    if (new_patch) load_patch(ncg_);
-
-    const float* __restrict__ pb = patch0 + (cg & 1) * PATCH_FLOATS + b_base + kh * PW;
-    const float* __restrict__ wb = wl0 + (s & 1) * W_FLOATS + a_base;
-#pragma unroll
-    for (int t = 0; t < CIQ; ++t) {
-#pragma unroll
-      for (int kw = 0; kw < KS; ++kw) {
-        float bf0 = pb[t * PS + kw];
-        float bf1 = pb[t * PS + kw + 16];
-        float af[MI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) af[mi] = wb[(t * KS + kw) * LDW + mi * 16];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf0, acc[mi][0], 0, 0, 0);
-          acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mi], bf1, acc[mi][1], 0, 0, 0);
-        }
-      }
+    if (more) {
+      NQ_LOAD_W(ncg_, nkh)
     }
-    if (more) store_w(wl0 + ((s + 1) & 1) * W_FLOATS);
-    if (new_patch) store_patch(patch0 + (ncg_ & 1) * PATCH_FLOATS);
+    if (new_patch) {
+      NQ_LOAD_PATCH(ncg_)
+    }
+
+    const float* __restrict__ pb = patch0 + ((cg - cg_lo) & 1) * PATCH_FLOATS + b_base + kh * PW;
+    const float* __restrict__ wb = wl0 + (s & 1) * W_FLOATS + a_base;
+    // software-pipelined fragments: the LDS reads of step st+1 are issued ahead of the MFMAs of step st
+    // (hipcc otherwise funnels every A fragment through one register pair and exposes the LDS latency
+    // after every 4 MFMAs); sched_barrier pins "reads of the next step, then MFMAs of this step".
+    {
+      constexpr int STEPS = CIQ * KS;
+      float af0[MI], af1[MI], bf0[2], bf1[2];
+#define NQ_LDFRAG(AF, BF, ST)                                                                         \
+  {                                                                                                   \
+    constexpr int t_ = (ST) / KS, kw_ = (ST)-t_ * KS;                                                 \
+    BF[0] = pb[t_ * PS + kw_];                                                                        \
+    BF[1] = pb[t_ * PS + kw_ + 16];                                                                   \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) AF[mi] = wb[(t_ * KS + kw_) * LDW + mi * 16];   \
+  }
+#define NQ_MFMAS(AF, BF)                                                                              \
+  _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                 \
+    acc[mi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF[mi], BF[0], acc[mi][0], 0, 0, 0);            \
+    acc[mi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF[mi], BF[1], acc[mi][1], 0, 0, 0);            \
+  }
+      NQ_LDFRAG(af0, bf0, 0)
+      igemm_steps<0, STEPS>([&](auto st_c) {
+        constexpr int st = decltype(st_c)::value;
+        if constexpr ((st & 1) == 0) {
+          if constexpr (st + 1 < STEPS) NQ_LDFRAG(af1, bf1, st + 1)
+          __builtin_amdgcn_sched_barrier(0);
+          NQ_MFMAS(af0, bf0)
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          if constexpr (st + 1 < STEPS) NQ_LDFRAG(af0, bf0, st + 1)
+          __builtin_amdgcn_sched_barrier(0);
+          NQ_MFMAS(af1, bf1)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+#undef NQ_LDFRAG
+#undef NQ_MFMAS
+    }
+    if (more) {
+      float* wdst = wl0 + ((s + 1) & 1) * W_FLOATS;
+      NQ_STORE_W(wdst)
+    }
+    if (new_patch) {
+      float* pdst = patch0 + ((ncg_ - cg_lo) & 1) * PATCH_FLOATS;
+      NQ_STORE_PATCH(pdst)
+    }
     __syncthreads();
     cg = ncg_;
     kh = nkh;
@@ -198,6 +236,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   const int py = y0 + wave;
   if (py >= H) return;
   const int Cout = a.Cout;
+  if (a.nsplit > 1) {  // raw partial sums; bias + epilogue are applied by conv_splitk_finish_kernel
+    float* __restrict__ slab = a.slab + ((int64_t)split * a.B + b) * Cout * H * W;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = co0 + mi * 16 + 4 * kq + reg;
+        if (co >= Cout) continue;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int px = x0 + ni * 16 + l16;
+          if (px < W) slab[((int64_t)co * H + py) * W + px] = acc[mi][ni][reg];
+        }
+      }
+    return;
+  }
   const int epi = a.epi;
   const int r = a.r, rr = a.r * a.r;
   const int64_t HW = (int64_t)H * W;
@@ -234,6 +288,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
+#if NQ_KS == 1
+// Sums the split-K slabs and applies bias + epilogue (one thread per conv output element, x fastest).
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(ConvArgs a) {
+  const int64_t HW = (int64_t)a.H * a.W;
+  const int64_t total = (int64_t)a.B * a.Cout * HW;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float v = 0.f;
+  for (int s = 0; s < a.nsplit; ++s) v += a.slab[s * total + i];
+  const int px = (int)(i % a.W);
+  const int py = (int)((i / a.W) % a.H);
+  const int co = (int)((i / HW) % a.Cout);
+  const int b = (int)(i / (HW * a.Cout));
+  if (a.bias) v += a.bias[co];
+  if (a.epi == NQ_EPI_PS_GELU) {
+    const int r = a.r, rr = r * r, C = a.Cout / rr;
+    const int c = co / rr, rem = co - c * rr, si = rem / r, sj = rem - si * r;
+    int64_t o = (((int64_t)b * C + c) * (a.H * r) + (int64_t)py * r + si) * ((int64_t)a.W * r) + (int64_t)px * r + sj;
+    a.z[o] = v;
+    a.y[o] = gelu_exact(v);
+  } else {
+    a.y[i] = (a.epi == NQ_EPI_TANH) ? tanhf(v) * 0.5f + 0.5f : v;
+  }
+}
+
+extern "C" int nq_conv_splitk_finish(const float* slab, const float* bias, float* y, float* z, int B, int H, int W, int Cout,
+                                     int r, int epi, int nsplit, hipStream_t st) {
+  ConvArgs a{};
+  a.slab = const_cast<float*>(slab); a.bias = bias; a.y = y; a.z = z;
+  a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.r = r; a.epi = epi; a.nsplit = nsplit;
+  int64_t total = (int64_t)B * Cout * H * W;
+  hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+  return nq_launch_status();
+}
+#endif
+
 template <int MI>
 int launch_igemm(const ConvArgs& a, int tiles, int co_tiles, hipStream_t st) {
   constexpr int MT = 16 * MI;
@@ -243,7 +333,7 @@ int launch_igemm(const ConvArgs& a, int tiles, int co_tiles, hipStream_t st) {
     return v;
   }();
   size_t lds = (size_t)(2 * PATCH_FLOATS + 2 * WROWS * LDW) * sizeof(float);
-  hipLaunchKernelGGL(conv_igemm_kernel<MI>, dim3((unsigned)tiles, (unsigned)co_tiles, (unsigned)a.B), dim3(256), lds, st,
+  hipLaunchKernelGGL(conv_igemm_kernel<MI>, dim3((unsigned)tiles, (unsigned)co_tiles, (unsigned)(a.B * a.nsplit)), dim3(256), lds, st,
                      a);
   return nq_launch_status();
 }
@@ -256,12 +346,14 @@ int launch_igemm(const ConvArgs& a, int tiles, int co_tiles, hipStream_t st) {
 // mi_sel: channel blocks (of 16) per workgroup, chosen by nq_conv_pick_mi().
 extern "C" int NQ_CAT(nq_conv_igemm_k, NQ_KS)(const float* x, const float* wt, const float* bias, float* y, float* z,
                                                int B, int Cin, int H, int W, int Cout, int ld, int r, int epi,
-                                               int mi_sel, hipStream_t st) {
+                                               int mi_sel, int nsplit, float* slab, hipStream_t st) {
   ConvArgs a;
   a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.z = z;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.ld = ld; a.r = r; a.epi = epi;
   a.tiles_x = (W + TW - 1) / TW;
   a.ncg = (Cin + CI - 1) / CI;
+  a.nsplit = nsplit;
+  a.slab = slab;
   int tiles = a.tiles_x * ((H + TH - 1) / TH);
   int co_tiles = (Cout + 16 * mi_sel - 1) / (16 * mi_sel);
   switch (mi_sel) {

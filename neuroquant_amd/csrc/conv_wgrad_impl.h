@@ -13,6 +13,8 @@
 // The bias gradient (row sums of dY) is accumulated by the n-tile-0 workgroups from the staged dY tile.
 //
 // Roofline: MFMA-bound; algorithmic flops = 2*Cout*Cin*KS^2*H*W*B.
+#include <type_traits>
+
 #include "nq_common.h"
 
 #ifndef NQ_KS
@@ -42,6 +44,14 @@ constexpr int PWS = [] {  // x row stride: >= SEG+KS-1 and == KS (mod 32)
   return v;
 }();
 constexpr int PSX = KS * PWS;  // plane stride (== KS*KS mod 32)
+
+template <int I0, int N, class F>
+__device__ __forceinline__ void wgrad_steps(F&& f) {
+  if constexpr (I0 < N) {
+    f(std::integral_constant<int, I0>{});
+    wgrad_steps<I0 + 1, N>(f);
+  }
+}
 
 template <int MI, int NI>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
@@ -145,18 +155,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
     store_seg();
     __syncthreads();
     if (seg + 1 < seg_hi) load_seg(seg + 1);  // in flight under the MFMAs below
-    // ---- 8 k-steps of 4 pixels ----
-#pragma unroll 2
-    for (int s = 0; s < 8; ++s) {
-      float bf[NI];
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) bf[ni] = xl[lc[ni] + pxo + s];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        float af = dzl[(mi * 16 + l16) * LDP + pxo + s];
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(af, bf[ni], acc[mi][ni], 0, 0, 0);
-      }
+    // ---- 8 k-steps of 4 pixels, fragments software-pipelined one step ahead (see conv_igemm_impl.h) ----
+    {
+      float af0[MI], af1[MI], bf0[NI], bf1[NI];
+#define NQ_LDFRAG(AF, BF, S)                                                                            \
+  {                                                                                                     \
+    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni) BF[ni] = xl[lc[ni] + pxo + (S)];                  \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) AF[mi] = dzl[(mi * 16 + l16) * LDP + pxo + (S)];  \
+  }
+#define NQ_MFMAS(AF, BF)                                                                                \
+  _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                   \
+    _Pragma("unroll") for (int ni = 0; ni < NI; ++ni)                                                   \
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(AF[mi], BF[ni], acc[mi][ni], 0, 0, 0);       \
+  }
+      NQ_LDFRAG(af0, bf0, 0)
+      wgrad_steps<0, 8>([&](auto st_c) {
+        constexpr int st = decltype(st_c)::value;
+        if constexpr ((st & 1) == 0) {
+          if constexpr (st + 1 < 8) NQ_LDFRAG(af1, bf1, st + 1)
+          __builtin_amdgcn_sched_barrier(0);
+          NQ_MFMAS(af0, bf0)
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          if constexpr (st + 1 < 8) NQ_LDFRAG(af0, bf0, st + 1)
+          __builtin_amdgcn_sched_barrier(0);
+          NQ_MFMAS(af1, bf1)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+#undef NQ_LDFRAG
+#undef NQ_MFMAS
     }
     if (do_db && tid < MT) {
       float sacc = 0.f;

@@ -19,6 +19,34 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# ---- optional per-launch timing with HIP events on the launch stream (bench.py's roofline object) ----
+_PROF = None
+
+
+def profile_start():
+    global _PROF
+    _PROF = {}
+
+
+def profile_stop():
+    """-> {key: (launches, total_ms)}; synchronises."""
+    global _PROF
+    prof, _PROF = _PROF, None
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(s.elapsed_time(e) for s, e in v)) for k, v in (prof or {}).items()}
+
+
+def _timed(key, fn):
+    if _PROF is None:
+        return fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    out = fn()
+    e.record()
+    _PROF.setdefault(key, []).append((s, e))
+    return out
+
+
 def _dev(t: torch.Tensor, name="tensor") -> torch.Tensor:
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(f"neuroquant_amd: {name} must live on the GPU (no CPU fallback exists)")
@@ -274,8 +302,11 @@ def conv_forward_raw(x, wt, dims, bias, cout, k, epilogue, r):
         z = torch.empty_like(y)
     else:
         y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
-    L.check(L.lib().nq_conv_forward(_p(x), _p(wt), _p(bias), _p(y), _p(z), B, cin, H, W, cout, k, dims[0], dims[1], r,
-                                    epilogue, _stream()), "conv_forward")
+    nws = L.lib().nq_conv_forward_ws_floats(B, cin, H, W, cout, k)
+    ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
+    _timed(("conv_igemm", k, cin, cout, H, W, B, epilogue),
+           lambda: L.check(L.lib().nq_conv_forward(_p(x), _p(wt), _p(bias), _p(y), _p(z), _p(ws), B, cin, H, W, cout, k,
+                                                   dims[0], dims[1], r, epilogue, _stream()), "conv_forward"))
     return y, z
 
 
@@ -284,7 +315,9 @@ def conv_wgrad_raw(x, dy, cout, k, want_db):
     ws = torch.empty(L.lib().nq_conv_wgrad_ws_floats(B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
     dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32)
     db = torch.empty(cout, device=x.device, dtype=torch.float32) if want_db else None
-    L.check(L.lib().nq_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k, _stream()), "conv_wgrad")
+    _timed(("conv_wgrad", k, cin, cout, H, W, B, 0),
+           lambda: L.check(L.lib().nq_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k, _stream()),
+                           "conv_wgrad"))
     return dw, db
 
 

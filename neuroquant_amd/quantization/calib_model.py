@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..utils import allreduce_mean_
 from .data_utils import LinearTempDecay
 from .quant_layer import QuantModule
 from .quant_model import QuantModel
@@ -123,12 +124,13 @@ class _Layer:
 def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: str = 'hnerv', batch_size: int = 8,
                          iters: int = 20000, weight: float = 0.01, opt_mode: str = 'mse', hadamard: bool = True,
                          b_range: tuple = (20, 2), warmup: float = 0.0, p: float = 2.0, lr: float = 0.0015,
-                         recorder: list = None, max_steps: int = None):
+                         recorder: list = None, max_steps: int = None, step_hook=None):
     """Network-wise calibration, in place (reference calib_model.py:92-240).
 
     gt: any sized iterable of dict batches {'img' (B,3,H,W), 'idx' (B,), 'norm_idx'}; cali_data[idx] feeds the
     decoder.  recorder (optional list) receives (total, round, b, count) per iteration -- this forces one host
-    sync per iteration and is meant for parity tests.  max_steps truncates the run (bench sampling).
+    sync per iteration and is meant for parity tests.  max_steps truncates the run and step_hook(done) is called
+    before every iteration (bench.py uses both to time exactly K steps).
     """
     if arch not in ('hnerv', 'nerv'):
         raise ValueError
@@ -143,6 +145,8 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
         if not L.m.bias_quantizer.inited:
             L.m.bias_quantizer(L.bias)
     done = 0
+    dp = torch.distributed.is_available() and torch.distributed.is_initialized() and \
+        torch.distributed.get_world_size() > 1
 
     def run(epochs, params, opt_lr, max_count, ada):
         nonlocal done
@@ -153,6 +157,8 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
         for _ in range(epochs):
             model.train()
             for sample in gt:
+                if step_hook is not None:
+                    step_hook(done)
                 if max_steps is not None and done >= max_steps:
                     return
                 img = sample['img'].to(device, non_blocking=True)
@@ -167,6 +173,8 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                 img_out, _, _ = model(inputs)
                 rec = ops.l2_loss(img_out, img)
                 rec.backward()
+                if dp:  # data-parallel: one all-reduce over the raw conv weight+bias gradients
+                    allreduce_mean_([t.grad for L in layers for t in (L.W, L.b)])
                 grads = []
                 for L in layers:
                     gW, gb = L.grads()

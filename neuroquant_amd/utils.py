@@ -1,0 +1,141 @@
+"""Host-side helpers around the hot loop: GPU-resident frame cache + batch loader (replaces the reference's
+PNG-decoding DataLoader, videosets/datasets.py + calibrate_network.py:153-165), PSNR (utils.py:148-155), data split
+(utils.py:42-53), config loading, synthetic Bunny-shaped frames for benchmarking, data-parallel helpers."""
+import logging
+import math
+import os
+import random
+
+import torch
+import yaml
+
+from . import ops
+
+
+def get_config(config_path):
+    with open(config_path, 'r') as stream:
+        return yaml.load(stream, Loader=yaml.FullLoader)
+
+
+def setup_logger(filename):
+    root = logging.getLogger()
+    root.setLevel(logging.INFO)
+    for h in list(root.handlers):
+        root.removeHandler(h)
+    fmt = logging.Formatter("%(message)s")
+    for h in (logging.FileHandler(filename) if filename else None, logging.StreamHandler()):
+        if h is not None:
+            h.setFormatter(fmt)
+            root.addHandler(h)
+
+
+def data_split(img_list, split_num_list, shuffle_data, rand_num=0):
+    valid_train_length, total_train_length, total_data_length = split_num_list
+    train, val = [], []
+    if shuffle_data:
+        random.Random(rand_num).shuffle(img_list)
+    for cur_i, frame_id in enumerate(img_list):
+        if (cur_i % total_data_length) < valid_train_length:
+            train.append(frame_id)
+        elif (cur_i % total_data_length) >= total_train_length:
+            val.append(frame_id)
+    return train, val
+
+
+def RoundTensor(x, num=2, group_str=False):
+    if group_str:
+        return '/'.join(','.join(str(round(ele, num)) for ele in x[i].tolist()) for i in range(x.size(0)))
+    return ','.join(str(round(ele, num)) for ele in x.flatten().tolist())
+
+
+def psnr_fn_single(output, gt):
+    """per-frame PSNR, -10*log10(mse + 1e-9) (reference utils.py:148-151), on the HIP reduction kernel."""
+    return ops.frame_psnr(output, gt).cpu()
+
+
+def psnr_fn_batch(output_list, gt):
+    return torch.stack([psnr_fn_single(o, gt) for o in output_list], 0).cpu()
+
+
+def synthetic_frames(n, h, w, seed=903, device='cuda'):
+    """Bunny-shaped synthetic video: per channel a sum of 8 low-frequency 2-D sinusoids that drift
+    with the frame index + N(0, 0.02) noise, clipped to [0,1] and quantised to k/255 -> uint8 (n,3,h,w)."""
+    g = torch.Generator(device='cpu').manual_seed(seed)
+    fx = torch.rand(3, 8, generator=g) * 6 + 0.5
+    fy = torch.rand(3, 8, generator=g) * 6 + 0.5
+    ph = torch.rand(3, 8, generator=g) * 2 * math.pi
+    amp = torch.rand(3, 8, generator=g) * 0.12 + 0.02
+    sp = torch.rand(3, 8, generator=g) * 0.2
+    yy, xx = torch.meshgrid(torch.linspace(0, 1, h, device=device), torch.linspace(0, 1, w, device=device), indexing='ij')
+    out = torch.empty((n, 3, h, w), dtype=torch.uint8, device=device)
+    gd = torch.Generator(device=device).manual_seed(seed)
+    fx, fy, ph, amp, sp = (t.to(device)[:, :, None, None] for t in (fx, fy, ph, amp, sp))
+    base = 2 * math.pi * (fx * xx + fy * yy) + ph                       # (3, 8, h, w)
+    for f in range(n):
+        img = 0.5 + (amp * torch.sin(base + sp * f)).sum(1)
+        img += 0.02 * torch.randn(img.shape, device=device, generator=gd)
+        out[f] = (img.clamp(0, 1) * 255).round().to(torch.uint8)
+    return out
+
+
+class FrameCache:
+    """All frames resident in HBM as uint8 (132 x 3 x 640 x 1280 = 324 MB); batches are produced by one HIP gather
+    kernel (img/255, videosets/datasets.py:23) -- no PNG decode, no H2D copy inside the calibration loop."""
+
+    def __init__(self, frames_u8: torch.Tensor):
+        assert frames_u8.dtype == torch.uint8 and frames_u8.is_cuda
+        self.frames = frames_u8.contiguous()
+
+    def __len__(self):
+        return self.frames.shape[0]
+
+    def batch(self, idx: torch.Tensor):
+        return ops.gather_frames_u8(self.frames, idx)
+
+
+class CacheLoader:
+    """`gt` for model_reconstruction: shuffle=True, drop_last=True batches of dicts {'img','idx','norm_idx'}
+    (calibrate_network.py:162-165) from a FrameCache.  With (rank, world) each rank yields its contiguous slice of
+    every global batch (data-parallel sharding); the order comes from a CPU generator seeded identically
+    on every rank, or from a recorded `order` array (epochs, batches, B)."""
+
+    def __init__(self, cache: FrameCache, indices, batch_size, seed=903, rank=0, world=1, order=None):
+        assert batch_size % world == 0, "global batch must divide across ranks"
+        self.cache, self.indices, self.bs = cache, list(indices), batch_size
+        self.gen = torch.Generator().manual_seed(seed)
+        self.rank, self.world, self.order, self.epoch = rank, world, order, 0
+        self.n_total = len(cache)
+
+    def __len__(self):
+        return len(self.indices) // self.bs if self.order is None else self.order.shape[1]
+
+    def __iter__(self):
+        if self.order is None:
+            perm = torch.randperm(len(self.indices), generator=self.gen)
+            sel = torch.tensor(self.indices)[perm][: len(self) * self.bs].view(len(self), self.bs)
+        else:
+            sel = torch.as_tensor(self.order[self.epoch % self.order.shape[0]], dtype=torch.int64)
+        self.epoch += 1
+        per = self.bs // self.world
+        dev = self.cache.frames.device
+        for row in sel:
+            idx = row[self.rank * per:(self.rank + 1) * per].to(dev)
+            yield {'img': self.cache.batch(idx), 'idx': idx, 'norm_idx': idx.float() / self.n_total}
+
+
+def allreduce_mean_(tensors, group=None):
+    """Data-parallel gradient exchange: ONE all-reduce(sum) over the flattened conv weight+bias gradients, then
+    1/world (each rank's loss is a local mean).  RCCL on GPU tensors, gloo on CPU tensors.  No-op when
+    torch.distributed is not initialised or world == 1."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return tensors
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(dist.get_world_size(group))
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n
+    return tensors
