@@ -118,16 +118,22 @@ int nq_conv_operand_dims(int Cin, int Cout, int k, int* krows, int* ld);
 #define NQ_EPI_PLAIN 0
 #define NQ_EPI_PS_GELU 1
 #define NQ_EPI_TANH 2
+#define NQ_EPI_PS 3         /* PixelShuffle(r) only: z = shuffled pre-activation; the consumer applies GELU on load */
+#define NQ_EPI_DGRAD_GELU 4 /* data gradient: y = conv * gelu'(zprev) (zprev (B,Cout,H,W)), stored PixelUnshuffle(r)-ed, i.e.
+                             * as the (B,Cout*r*r,H/r,W/r) output gradient of the convolution below */
 int64_t nq_conv_forward_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
+/* in_gelu != 0: x holds pre-activations and exact GELU is applied while the input tile is staged (the activation
+ * tensor itself is never written). */
 int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y, float* z, float* ws, int B, int Cin, int H,
-                    int W, int Cout, int k, int krows, int ld, int r, int epilogue, nq_stream_t stream);
+                    int W, int Cout, int k, int krows, int ld, int r, int epilogue, int in_gelu, const float* zprev,
+                    nq_stream_t stream);
 
 /* Weight + bias gradient of the same convolution: dw (Cout,Cin,k,k), db (Cout) (db may be NULL),
  * from x (B,Cin,H,W) and dy (B,Cout,H,W).  ws: scratch of >= nq_conv_wgrad_ws_floats(...) floats.
- * Deterministic (fixed split-K order). */
+ * x_gelu != 0: x holds pre-activations, exact GELU is applied while staging.  Deterministic (fixed split-K order). */
 int64_t nq_conv_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
 int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
-                  int k, nq_stream_t stream);
+                  int k, int x_gelu, nq_stream_t stream);
 
 /* Backward of PixelShuffle(r)+GELU: dconv (B,C*r*r,H,W) = unshuffle(da * gelu'(z)), da and z are (B,C,H*r,W*r). */
 int nq_ps_gelu_backward(const float* da, const float* z, float* dconv, int B, int C, int H, int W, int r,

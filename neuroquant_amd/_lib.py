@@ -8,7 +8,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnqhip.so")
 
 NQ_OK = 0
-EPI_PLAIN, EPI_PS_GELU, EPI_TANH = 0, 1, 2
+EPI_PLAIN, EPI_PS_GELU, EPI_TANH, EPI_PS, EPI_DGRAD_GELU = 0, 1, 2, 3, 4
 
 
 class NQLibraryError(RuntimeError):
@@ -44,9 +44,9 @@ def _load():
     sig("nq_weight_layouts", I, P, P, P, I, I, I, I, I, I, I, P)
     sig("nq_conv_operand_dims", I, I, I, I, POINTER(c_int), POINTER(c_int))
     sig("nq_conv_forward_ws_floats", L, I, I, I, I, I, I)
-    sig("nq_conv_forward", I, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, P)
+    sig("nq_conv_forward", I, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P)
     sig("nq_conv_wgrad_ws_floats", L, I, I, I, I, I, I)
-    sig("nq_conv_wgrad", I, P, P, P, P, P, I, I, I, I, I, I, P)
+    sig("nq_conv_wgrad", I, P, P, P, P, P, I, I, I, I, I, I, I, P)
     sig("nq_ps_gelu_backward", I, P, P, P, I, I, I, I, I, P)
     sig("nq_tanh_out_backward", I, P, P, P, L, P)
     sig("nq_l2_loss", I, P, P, P, P, P, L, L, F, P)

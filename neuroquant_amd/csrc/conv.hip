@@ -4,18 +4,19 @@
 
 extern "C" {
 int nq_conv_igemm_k1(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int,
-                     int, float*, hipStream_t);
+                     int, float*, int, const float*, hipStream_t);
 int nq_conv_igemm_k3(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int,
-                     int, float*, hipStream_t);
+                     int, float*, int, const float*, hipStream_t);
 int nq_conv_igemm_k5(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int,
-                     int, float*, hipStream_t);
-int nq_conv_splitk_finish(const float*, const float*, float*, float*, int, int, int, int, int, int, int, hipStream_t);
+                     int, float*, int, const float*, hipStream_t);
+int nq_conv_splitk_finish(const float*, const float*, float*, float*, const float*, int, int, int, int, int, int, int,
+                          hipStream_t);
 int nq_conv_wgrad_k1(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
-                     hipStream_t);
+                     int, hipStream_t);
 int nq_conv_wgrad_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
-                     hipStream_t);
+                     int, hipStream_t);
 int nq_conv_wgrad_k5(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
-                     hipStream_t);
+                     int, hipStream_t);
 }
 
 namespace {
@@ -172,11 +173,14 @@ int64_t nq_conv_forward_ws_floats(int B, int Cin, int H, int W, int Cout, int k)
 }
 
 int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y, float* z, float* ws, int B, int Cin, int H,
-                    int W, int Cout, int k, int krows, int ld, int r, int epilogue, nq_stream_t stream) {
-  if (!x || !wt || !y || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
+                    int W, int Cout, int k, int krows, int ld, int r, int epilogue, int in_gelu, const float* zprev,
+                    nq_stream_t stream) {
+  if (!x || !wt || (!y && epilogue != NQ_EPI_PS) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0)
+    return NQ_ERR_INVALID;
   if (!ks_ok(k)) return NQ_ERR_UNSUPPORTED;
-  if (epilogue == NQ_EPI_PS_GELU && (!z || r <= 0 || Cout % (r * r) != 0)) return NQ_ERR_INVALID;
-  if (epilogue < 0 || epilogue > NQ_EPI_TANH) return NQ_ERR_INVALID;
+  if (epilogue < 0 || epilogue > NQ_EPI_DGRAD_GELU) return NQ_ERR_INVALID;
+  if ((epilogue == NQ_EPI_PS_GELU || epilogue == NQ_EPI_PS) && (!z || r <= 0 || Cout % (r * r) != 0)) return NQ_ERR_INVALID;
+  if (epilogue == NQ_EPI_DGRAD_GELU && (!zprev || r <= 0 || H % r != 0 || W % r != 0)) return NQ_ERR_INVALID;
   int need_rows, need_ld;
   nq_conv_operand_dims(Cin, Cout, k, &need_rows, &need_ld);
   if (krows < need_rows || ld < need_ld || (ld & 3)) return NQ_ERR_INVALID;
@@ -188,12 +192,12 @@ int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y
   hipStream_t st = nq_s(stream);
   int rc;
   switch (k) {
-    case 1: rc = nq_conv_igemm_k1(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, ns, ws, st); break;
-    case 3: rc = nq_conv_igemm_k3(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, ns, ws, st); break;
-    default: rc = nq_conv_igemm_k5(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, ns, ws, st); break;
+    case 1: rc = nq_conv_igemm_k1(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, ns, ws, in_gelu, zprev, st); break;
+    case 3: rc = nq_conv_igemm_k3(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, ns, ws, in_gelu, zprev, st); break;
+    default: rc = nq_conv_igemm_k5(x, wt, bias, y, z, B, Cin, H, W, Cout, ld, r, epilogue, mi, ns, ws, in_gelu, zprev, st); break;
   }
   if (rc != NQ_OK || ns == 1) return rc;
-  return nq_conv_splitk_finish(ws, bias, y, z, B, H, W, Cout, r, epilogue, ns, st);
+  return nq_conv_splitk_finish(ws, bias, y, z, zprev, B, H, W, Cout, r, epilogue, ns, st);
 }
 
 int64_t nq_conv_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
@@ -203,7 +207,7 @@ int64_t nq_conv_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
 }
 
 int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
-                  int k, nq_stream_t stream) {
+                  int k, int x_gelu, nq_stream_t stream) {
   if (!x || !dy || !dw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
   if (!ks_ok(k)) return NQ_ERR_UNSUPPORTED;
   WgradPlan p = plan_wgrad(B, Cin, H, W, Cout, k);
@@ -212,9 +216,9 @@ int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* 
   hipStream_t st = nq_s(stream);
   int rc;
   switch (k) {
-    case 1: rc = nq_conv_wgrad_k1(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, st); break;
-    case 3: rc = nq_conv_wgrad_k3(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, st); break;
-    default: rc = nq_conv_wgrad_k5(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, st); break;
+    case 1: rc = nq_conv_wgrad_k1(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, x_gelu, st); break;
+    case 3: rc = nq_conv_wgrad_k3(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, x_gelu, st); break;
+    default: rc = nq_conv_wgrad_k5(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, x_gelu, st); break;
   }
   if (rc != NQ_OK) return rc;
   const int N = Cin * k * k;

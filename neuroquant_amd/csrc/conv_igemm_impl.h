@@ -37,7 +37,8 @@ struct ConvArgs {
   const float* bias;
   float* y;
   float* z;
-  int B, Cin, H, W, Cout, ld, r, epi, tiles_x, ncg, nsplit;
+  int B, Cin, H, W, Cout, ld, r, epi, tiles_x, ncg, nsplit, in_gelu;
+  const float* zprev;  // NQ_EPI_DGRAD_GELU: pre-activation of the layer below, (B,Cout,H,W)
   float* slab;  // [nsplit][B][Cout][H][W] partial sums when nsplit > 1
 };
 
@@ -70,6 +71,12 @@ __device__ __forceinline__ void igemm_steps(F&& f) {
 
 __device__ __forceinline__ float gelu_exact(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
 
+__device__ __forceinline__ float gelu_grad_exact(float v) {
+  float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
 template <int MI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_igemm_kernel(ConvArgs a) {
   constexpr int MT = 16 * MI;
@@ -97,6 +104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const float* __restrict__ xb = a.x + (int64_t)b * Cin * H * W;
   const float* __restrict__ wt = a.wt + co0;
   const int ld = a.ld;
+  const bool in_gelu = a.in_gelu != 0;  // the input is a pre-activation: apply GELU while staging (gelu(0)=0 keeps the halo)
 
   // ---- staging helpers ------------------------------------------------------------------------
   float pv[PPT];
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 #define NQ_STORE_PATCH(DST)                                                                       \
   _Pragma("unroll") for (int i = 0; i < PPT; ++i) {                                               \
-    if (plds[i] >= 0) (DST)[plds[i]] = pv[i];                                                     \
+    if (plds[i] >= 0) (DST)[plds[i]] = in_gelu ? gelu_exact(pv[i]) : pv[i];                       \
   }
 #define NQ_LOAD_W(CG, KH)                                                                         \
   _Pragma("unroll") for (int i = 0; i < WPT; ++i) {                                               \
@@ -238,32 +246,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int Cout = a.Cout;
   if (a.nsplit > 1) {  // raw partial sums; bias + epilogue are applied by conv_splitk_finish_kernel
     float* __restrict__ slab = a.slab + ((int64_t)split * a.B + b) * Cout * H * W;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+    igemm_steps<0, MI>([&](auto mi_c) {
+      constexpr int mi = decltype(mi_c)::value;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int co = co0 + mi * 16 + 4 * kq + reg;
-        if (co >= Cout) continue;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
           const int px = x0 + ni * 16 + l16;
-          if (px < W) slab[((int64_t)co * H + py) * W + px] = acc[mi][ni][reg];
+          if (co < Cout && px < W) slab[((int64_t)co * H + py) * W + px] = acc[mi][ni][reg];
         }
       }
+    });
     return;
   }
   const int epi = a.epi;
   const int r = a.r, rr = a.r * a.r;
   const int64_t HW = (int64_t)H * W;
+  const int cob = co0 + 4 * kq;  // this lane's first channel of block mi is cob + 16*mi (multiple of 4)
+  if ((epi == NQ_EPI_PS || epi == NQ_EPI_PS_GELU) && (r == 2 || r == 4)) {
+    // PixelShuffle fast paths: the 4 registers of a lane are 4 consecutive conv channels = a full 2x2 output
+    // block (r=2) or one output row segment of 4 pixels (r=4) -> 8/16-byte stores, contiguous across lanes
+    const int C = Cout / rr;
+    const bool want_act = (epi == NQ_EPI_PS_GELU);
+    igemm_steps<0, MI>([&](auto mi_c) {
+      constexpr int mi = decltype(mi_c)::value;
+      const int co = cob + mi * 16;
+      if (co >= Cout) return;  // Cout % 4 == 0 for r in {2,4}
+      const float4 bv = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int c = co / rr;
+      const int si = (r == 4) ? ((co >> 2) & 3) : 0;
+      const int64_t rowbase = (((int64_t)b * C + c) * (H * r) + (int64_t)py * r + si) * ((int64_t)W * r);
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+      for (int ni = 0; ni < 2; ++ni) {
+        const int px = x0 + ni * 16 + l16;
+        if (px >= W) continue;
+        const f32x4 v = acc[mi][ni];
+        const float v0 = v[0] + bv.x, v1 = v[1] + bv.y, v2 = v[2] + bv.z, v3 = v[3] + bv.w;
+        if (r == 2) {
+          const int64_t o0 = rowbase + (int64_t)px * 2, o1 = o0 + (int64_t)W * 2;
+          *reinterpret_cast<float2*>(a.z + o0) = make_float2(v0, v1);
+          *reinterpret_cast<float2*>(a.z + o1) = make_float2(v2, v3);
+          if (want_act) {
+            *reinterpret_cast<float2*>(a.y + o0) = make_float2(gelu_exact(v0), gelu_exact(v1));
+            *reinterpret_cast<float2*>(a.y + o1) = make_float2(gelu_exact(v2), gelu_exact(v3));
+          }
+        } else {
+          const int64_t o0 = rowbase + (int64_t)px * 4;
+          *reinterpret_cast<float4*>(a.z + o0) = make_float4(v0, v1, v2, v3);
+          if (want_act)
+            *reinterpret_cast<float4*>(a.y + o0) = make_float4(gelu_exact(v0), gelu_exact(v1), gelu_exact(v2), gelu_exact(v3));
+        }
+      }
+    });
+    return;
+  }
+  igemm_steps<0, MI>([&](auto mi_c) {
+    constexpr int mi = decltype(mi_c)::value;
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
-      const int co = co0 + mi * 16 + 4 * kq + reg;
+      const int co = cob + mi * 16 + reg;
       if (co >= Cout) continue;
       const float bv = a.bias ? a.bias[co] : 0.f;
       int c = 0, si = 0, sj = 0;
-      if (epi == NQ_EPI_PS_GELU) {
+      if (epi == NQ_EPI_PS_GELU || epi == NQ_EPI_PS) {
         c = co / rr;
         int rem = co - c * rr;
         si = rem / r;
@@ -274,18 +320,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int px = x0 + ni * 16 + l16;
         if (px >= W) continue;
         float v = acc[mi][ni][reg] + bv;
-        if (epi == NQ_EPI_PS_GELU) {
+        if (epi == NQ_EPI_PS_GELU || epi == NQ_EPI_PS) {
           const int C = Cout / rr;
           int64_t o = (((int64_t)b * C + c) * (H * r) + (int64_t)py * r + si) * ((int64_t)W * r) + (int64_t)px * r + sj;
           a.z[o] = v;
-          a.y[o] = gelu_exact(v);
+          if (epi == NQ_EPI_PS_GELU) a.y[o] = gelu_exact(v);
+        } else if (epi == NQ_EPI_DGRAD_GELU) {
+          // data gradient w.r.t. the pre-activation below: acc * gelu'(z), stored un-shuffled (conv layout of the
+          // layer below: channel c*r*r + (y%r)*r + x%r at (y/r, x/r)); r == 1 keeps the layout
+          const int64_t i = ((int64_t)b * Cout + co) * HW + (int64_t)py * W + px;
+          v *= gelu_grad_exact(a.zprev[i]);
+          if (r == 1) {
+            a.y[i] = v;
+          } else {
+            const int yq = py / r, xq = px / r;
+            const int ch = co * rr + (py - yq * r) * r + (px - xq * r);
+            a.y[(((int64_t)b * Cout * rr + ch) * (H / r) + yq) * (int64_t)(W / r) + xq] = v;
+          }
         } else {
           int64_t o = ((int64_t)b * Cout + co) * HW + (int64_t)py * W + px;
           a.y[o] = (epi == NQ_EPI_TANH) ? tanhf(v) * 0.5f + 0.5f : v;
         }
       }
     }
-  }
+  });
 }
 
 #if NQ_KS == 1
@@ -302,21 +360,31 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(ConvArgs a) {
   const int co = (int)((i / HW) % a.Cout);
   const int b = (int)(i / (HW * a.Cout));
   if (a.bias) v += a.bias[co];
-  if (a.epi == NQ_EPI_PS_GELU) {
+  if (a.epi == NQ_EPI_PS_GELU || a.epi == NQ_EPI_PS) {
     const int r = a.r, rr = r * r, C = a.Cout / rr;
     const int c = co / rr, rem = co - c * rr, si = rem / r, sj = rem - si * r;
     int64_t o = (((int64_t)b * C + c) * (a.H * r) + (int64_t)py * r + si) * ((int64_t)a.W * r) + (int64_t)px * r + sj;
     a.z[o] = v;
-    a.y[o] = gelu_exact(v);
+    if (a.epi == NQ_EPI_PS_GELU) a.y[o] = gelu_exact(v);
+  } else if (a.epi == NQ_EPI_DGRAD_GELU) {
+    const int r = a.r, rr = r * r;
+    v *= gelu_grad_exact(a.zprev[i]);
+    if (r == 1) {
+      a.y[i] = v;
+    } else {
+      const int yq = py / r, xq = px / r;
+      const int ch = co * rr + (py - yq * r) * r + (px - xq * r);
+      a.y[(((int64_t)b * a.Cout * rr + ch) * (a.H / r) + yq) * (int64_t)(a.W / r) + xq] = v;
+    }
   } else {
     a.y[i] = (a.epi == NQ_EPI_TANH) ? tanhf(v) * 0.5f + 0.5f : v;
   }
 }
 
-extern "C" int nq_conv_splitk_finish(const float* slab, const float* bias, float* y, float* z, int B, int H, int W, int Cout,
-                                     int r, int epi, int nsplit, hipStream_t st) {
+extern "C" int nq_conv_splitk_finish(const float* slab, const float* bias, float* y, float* z, const float* zprev, int B,
+                                     int H, int W, int Cout, int r, int epi, int nsplit, hipStream_t st) {
   ConvArgs a{};
-  a.slab = const_cast<float*>(slab); a.bias = bias; a.y = y; a.z = z;
+  a.slab = const_cast<float*>(slab); a.bias = bias; a.y = y; a.z = z; a.zprev = zprev;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.r = r; a.epi = epi; a.nsplit = nsplit;
   int64_t total = (int64_t)B * Cout * H * W;
   hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
@@ -346,7 +414,8 @@ int launch_igemm(const ConvArgs& a, int tiles, int co_tiles, hipStream_t st) {
 // mi_sel: channel blocks (of 16) per workgroup, chosen by nq_conv_pick_mi().
 extern "C" int NQ_CAT(nq_conv_igemm_k, NQ_KS)(const float* x, const float* wt, const float* bias, float* y, float* z,
                                                int B, int Cin, int H, int W, int Cout, int ld, int r, int epi,
-                                               int mi_sel, int nsplit, float* slab, hipStream_t st) {
+                                               int mi_sel, int nsplit, float* slab, int in_gelu, const float* zprev,
+                                               hipStream_t st) {
   ConvArgs a;
   a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.z = z;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.ld = ld; a.r = r; a.epi = epi;
@@ -354,6 +423,8 @@ extern "C" int NQ_CAT(nq_conv_igemm_k, NQ_KS)(const float* x, const float* wt, c
   a.ncg = (Cin + CI - 1) / CI;
   a.nsplit = nsplit;
   a.slab = slab;
+  a.in_gelu = in_gelu;
+  a.zprev = zprev;
   int tiles = a.tiles_x * ((H + TH - 1) / TH);
   int co_tiles = (Cout + 16 * mi_sel - 1) / (16 * mi_sel);
   switch (mi_sel) {

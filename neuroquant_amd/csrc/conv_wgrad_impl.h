@@ -30,7 +30,7 @@ struct WgradArgs {
   const float* dy;
   float* slab;     // [nsplit][co_pad][n_pad]
   float* slab_db;  // [nsplit][co_pad]
-  int B, Cin, H, W, Cout, N, co_pad, n_pad, segs_x, nseg, nsplit;
+  int B, Cin, H, W, Cout, N, co_pad, n_pad, segs_x, nseg, nsplit, x_gelu;
 };
 
 constexpr int KS = NQ_KS;
@@ -44,6 +44,8 @@ constexpr int PWS = [] {  // x row stride: >= SEG+KS-1 and == KS (mod 32)
   return v;
 }();
 constexpr int PSX = KS * PWS;  // plane stride (== KS*KS mod 32)
+
+__device__ __forceinline__ float wgrad_gelu(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
 
 template <int I0, int N, class F>
 __device__ __forceinline__ void wgrad_steps(F&& f) {
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
       if (e < XE) {
         int ci = e / (KS * (SEG + KS - 1)), rem = e - ci * (KS * (SEG + KS - 1));
         int r = rem / (SEG + KS - 1), c = rem - r * (SEG + KS - 1);
-        xl[ci * PSX + r * PWS + c] = xv[i];
+        xl[ci * PSX + r * PWS + c] = a.x_gelu ? wgrad_gelu(xv[i]) : xv[i];
       }
     }
   };
@@ -230,7 +232,7 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
 // (mi_sel, ni_sel) chosen by nq_wgrad_pick(); co_pad % (16*mi) == 0 and n_pad % (64*ni) == 0.
 extern "C" int NQ_CAT(nq_conv_wgrad_k, NQ_KS)(const float* x, const float* dy, float* slab, float* slab_db, int B,
                                                int Cin, int H, int W, int Cout, int co_pad, int n_pad, int nsplit,
-                                               int mi_sel, int ni_sel, hipStream_t st) {
+                                               int mi_sel, int ni_sel, int x_gelu, hipStream_t st) {
   WgradArgs a;
   a.x = x; a.dy = dy; a.slab = slab; a.slab_db = slab_db;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.N = Cin * KK;
@@ -238,6 +240,7 @@ extern "C" int NQ_CAT(nq_conv_wgrad_k, NQ_KS)(const float* x, const float* dy, f
   a.segs_x = (W + SEG - 1) / SEG;
   a.nseg = a.segs_x * H * B;
   a.nsplit = nsplit;
+  a.x_gelu = x_gelu;
 #define NQ_WG_CASE(MI_) \
   if (mi_sel == MI_ && ni_sel == ni_for(MI_)) return launch_wgrad<MI_, ni_for(MI_)>(a, st);
   NQ_WG_CASE(1)

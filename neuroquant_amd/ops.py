@@ -12,7 +12,8 @@ from torch.autograd import Function
 
 from . import _lib as L
 
-EPI_PLAIN, EPI_PS_GELU, EPI_TANH = L.EPI_PLAIN, L.EPI_PS_GELU, L.EPI_TANH
+EPI_PLAIN, EPI_PS_GELU, EPI_TANH, EPI_PS, EPI_DGRAD_GELU = (L.EPI_PLAIN, L.EPI_PS_GELU, L.EPI_TANH, L.EPI_PS,
+                                                                L.EPI_DGRAD_GELU)
 
 
 def _stream():
@@ -294,30 +295,36 @@ def weight_layouts(w, need_bwd):
     return wt, (kf, lf), wb, (kb, lb)
 
 
-def conv_forward_raw(x, wt, dims, bias, cout, k, epilogue, r):
+def conv_forward_raw(x, wt, dims, bias, cout, k, epilogue, r, in_gelu=False, zprev=None):
+    """One nq_conv_forward launch.  Returns (y, z): z = shuffled pre-activation for the PixelShuffle epilogues
+    (y is None for EPI_PS), y = un-shuffled gradient for EPI_DGRAD_GELU."""
     B, cin, H, W = x.shape
-    z = None
-    if epilogue == EPI_PS_GELU:
-        y = torch.empty((B, cout // (r * r), H * r, W * r), device=x.device, dtype=torch.float32)
-        z = torch.empty_like(y)
+    y = z = None
+    if epilogue in (EPI_PS_GELU, EPI_PS):
+        z = torch.empty((B, cout // (r * r), H * r, W * r), device=x.device, dtype=torch.float32)
+        if epilogue == EPI_PS_GELU:
+            y = torch.empty_like(z)
+    elif epilogue == EPI_DGRAD_GELU:
+        y = torch.empty((B, cout * r * r, H // r, W // r), device=x.device, dtype=torch.float32)
     else:
         y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
     nws = L.lib().nq_conv_forward_ws_floats(B, cin, H, W, cout, k)
     ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
     _timed(("conv_igemm", k, cin, cout, H, W, B, epilogue),
            lambda: L.check(L.lib().nq_conv_forward(_p(x), _p(wt), _p(bias), _p(y), _p(z), _p(ws), B, cin, H, W, cout, k,
-                                                   dims[0], dims[1], r, epilogue, _stream()), "conv_forward"))
+                                                   dims[0], dims[1], r, epilogue, 1 if in_gelu else 0, _p(zprev),
+                                                   _stream()), "conv_forward"))
     return y, z
 
 
-def conv_wgrad_raw(x, dy, cout, k, want_db):
+def conv_wgrad_raw(x, dy, cout, k, want_db, x_gelu=False):
     B, cin, H, W = x.shape
     ws = torch.empty(L.lib().nq_conv_wgrad_ws_floats(B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
     dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32)
     db = torch.empty(cout, device=x.device, dtype=torch.float32) if want_db else None
     _timed(("conv_wgrad", k, cin, cout, H, W, B, 0),
-           lambda: L.check(L.lib().nq_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k, _stream()),
-                           "conv_wgrad"))
+           lambda: L.check(L.lib().nq_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k,
+                                                 1 if x_gelu else 0, _stream()), "conv_wgrad"))
     return dw, db
 
 
@@ -364,6 +371,115 @@ class _ConvFn(Function):
 
 def conv2d_fused(x, w, b, epilogue=EPI_PLAIN, r=1):
     return _ConvFn.apply(x, w, b, epilogue, r)
+
+
+class DecoderSpec:
+    """Static description of a conv decoder stack for `decoder_stack`: per layer (k, shuffle r, gelu after),
+    the (fc_h, fc_w) channel->space reshape after layer 0 and whether OutImg is tanh*0.5+0.5."""
+
+    def __init__(self, layers, fc_hw=(1, 1), tanh_out=True, materialize_act=True):
+        self.layers = [tuple(l) for l in layers]
+        self.fc_hw = tuple(fc_hw)
+        self.tanh_out = tanh_out
+        # True : each block's epilogue writes z AND a = gelu(z); consumers read a (one erf per element).
+        # False: only z is written and every consumer applies GELU while staging its tile (less HBM traffic, but the
+        #        halo / per-tap re-reads repeat the erf 2-6x; measured slower on MI355X, kept for comparison).
+        self.materialize_act = materialize_act
+
+
+def _space_from_channels(x, fh, fw):
+    n, c, h, w = x.shape  # reference NeRV.py:49-51
+    return x.view(n, -1, fh, fw, h, w).permute(0, 1, 4, 2, 5, 3).reshape(n, -1, fh * h, fw * w)
+
+
+def _channels_from_space(g, fh, fw):
+    n, c, hh, ww = g.shape
+    return g.view(n, c, hh // fh, fh, ww // fw, fw).permute(0, 1, 3, 5, 2, 4).reshape(n, c * fh * fw, hh // fh, ww // fw)
+
+
+class _DecoderStackFn(Function):
+    """Whole decoder (reference HNeRV.py:49-71 / NeRV.py:44-65) as ONE autograd node with an explicit schedule.
+
+    Only pre-activations are ever written: every conv stores PixelShuffle(conv+bias) (EPI_PS) and the next conv /
+    the weight-gradient kernel apply exact GELU while staging their input tile; the data-gradient kernel multiplies
+    by gelu'(z) and un-shuffles in its epilogue (EPI_DGRAD_GELU).  So per block: 1 launch forward, 2 backward
+    (+ the tiny split-K reductions), no elementwise passes over activations.
+    """
+
+    @staticmethod
+    def forward(ctx, emb, spec, *wb):
+        x = _dev(emb, "embedding")
+        n = len(spec.layers)
+        saved_in, saved_z, metas = [], [], []
+        in_gelu = False      # x currently holds pre-activations that still need GELU (materialize_act=False only)
+        zprev = None         # pre-activation behind x (for gelu' in the data gradient)
+        for l, (k, r, act) in enumerate(spec.layers):
+            W = _dev(wb[2 * l], "weight")
+            b = _dev(wb[2 * l + 1], "bias") if wb[2 * l + 1] is not None else None
+            cout, cin = W.shape[0], W.shape[1]
+            wt, dims, wbk, dims_b = weight_layouts(W, need_bwd=(l > 0))
+            last = l == n - 1
+            if last:
+                epi = EPI_TANH if spec.tanh_out else EPI_PLAIN
+            elif act:
+                epi = EPI_PS_GELU if spec.materialize_act else EPI_PS
+            elif r > 1:
+                epi = EPI_PS
+            else:
+                epi = EPI_PLAIN
+            y, z = conv_forward_raw(x, wt, dims, b, cout, k, epi, r, in_gelu=in_gelu)
+            saved_in.append(x)
+            saved_z.append(zprev)
+            metas.append((k, r, act, cout, cin, in_gelu, wbk, dims_b, b is not None))
+            if epi == EPI_PS_GELU:
+                x, zprev, in_gelu = y, z, False
+            elif epi == EPI_PS:
+                x, zprev, in_gelu = z, z, act
+            else:
+                x, zprev, in_gelu = y, None, False
+            if l == 0 and spec.fc_hw != (1, 1):
+                x = _space_from_channels(x, *spec.fc_hw).contiguous()
+        ctx.spec, ctx.metas, ctx.n = spec, metas, n
+        ctx.save_for_backward(x, *saved_in, *saved_z)
+        return x
+
+    @staticmethod
+    def backward(ctx, g_img):
+        spec, metas, n = ctx.spec, ctx.metas, ctx.n
+        saved = ctx.saved_tensors
+        img, xs, zs = saved[0], saved[1:1 + n], saved[1 + n:]
+        g = _dev(g_img, "grad")
+        if spec.tanh_out:
+            dconv = torch.empty_like(g)
+            L.check(L.lib().nq_tanh_out_backward(_p(g), _p(img), _p(dconv), g.numel(), _stream()), "tanh_backward")
+        else:
+            dconv = g
+        grads = [None] * (2 * n)
+        for l in range(n - 1, -1, -1):
+            k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b = metas[l]
+            x_in = xs[l]
+            dw, db = conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu)
+            grads[2 * l], grads[2 * l + 1] = dw, db
+            if l == 0:
+                break
+            kp, rp, actp = spec.layers[l - 1]
+            if actp:   # the layer below ends in GELU: d(pre-activation) = dgrad * gelu'(z), stored as ITS conv-output grad
+                dconv, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, EPI_DGRAD_GELU, rp, zprev=zs[l])
+            else:
+                if rp != 1:
+                    raise NotImplementedError("PixelShuffle without activation between decoder layers")
+                dconv, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, EPI_PLAIN, 1)
+                if l == 1 and spec.fc_hw != (1, 1):
+                    dconv = _channels_from_space(dconv, *spec.fc_hw).contiguous()
+        return (None, None) + tuple(grads)
+
+
+def decoder_stack(emb, spec: DecoderSpec, weights):
+    """weights: [(W, b), ...] per layer (already fake-quantised).  Returns the output image."""
+    flat = []
+    for W, b in weights:
+        flat += [W, b]
+    return _DecoderStackFn.apply(emb, spec, *flat)
 
 
 # ------------------------------------------------------------------------------------------ loss / metrics / frames
