@@ -32,7 +32,7 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert lib.nq_fwht(ctypes.c_void_p(16), ctypes.c_void_p(32), 1, 12, 1, 12, 12, n) == -1      # not a power of two
     assert lib.nq_fwht(ctypes.c_void_p(16), ctypes.c_void_p(32), 1, 2048, 1, 8, 8, n) == -2      # too long
     assert lib.nq_conv_forward(ctypes.c_void_p(16), ctypes.c_void_p(16), n, ctypes.c_void_p(16), n, n, 1, 4, 8, 8, 4, 7, 196,
-                               16, 1, 0, n) == -2                                             # k=7 not built
+                               16, 1, 0, 0, n, n) == -2                                       # k=7 not built
     assert lib.nq_conv_forward_ws_floats(2, 44, 320, 640, 148, 5) == 0                        # enough tiles: no split-K
     assert lib.nq_conv_forward_ws_floats(2, 848, 40, 80, 64, 5) > 0                           # dec3 data gradient: split-K
     kr, ld = ctypes.c_int(), ctypes.c_int()
