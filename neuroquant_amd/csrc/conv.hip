@@ -1,5 +1,7 @@
 // C-ABI entry points of the convolution side: tile selection + dispatch to the per-kernel-size
 // implicit-GEMM / weight-gradient kernels, weight re-layout, split-K slab reduction.
+#include <algorithm>
+
 #include "nq_common.h"
 
 extern "C" {
@@ -11,6 +13,11 @@ int nq_conv_igemm_k5(const float*, const float*, const float*, float*, float*, i
                      int, float*, int, const float*, hipStream_t);
 int nq_conv_splitk_finish(const float*, const float*, float*, float*, const float*, int, int, int, int, int, int, int,
                           hipStream_t);
+int nq_head_supported(int, int);
+int nq_head_forward(const float*, const float*, int, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+int nq_head_dgrad(const float*, const float*, int, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+int64_t nq_head_wgrad_ws_floats(int, int, int, int, int, int);
+int nq_head_wgrad(const float*, const float*, float*, float*, float*, int, int, int, int, int, int, int, hipStream_t);
 int nq_conv_wgrad_k1(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
                      int, hipStream_t);
 int nq_conv_wgrad_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
@@ -50,6 +57,16 @@ inline int pick_nsplit(int B, int Cin, int H, int W, int Cout, int k) {
   if (ns > ncg) ns = ncg;
   if (ns > 32) ns = 32;
   return ns < 1 ? 1 : ns;
+}
+
+inline bool use_head_fwd(int Cout, int k, int epi, int in_gelu) {
+  return nq_head_supported(Cout, k) && (epi == NQ_EPI_PLAIN || epi == NQ_EPI_TANH) && !in_gelu;
+}
+inline bool use_head_dgrad(int Cin, int k, int epi, int in_gelu, const float* bias) {
+  return nq_head_supported(Cin, k) && (epi == NQ_EPI_PLAIN || epi == NQ_EPI_DGRAD_GELU) && !in_gelu && !bias;
+}
+inline bool use_head_wgrad(int Cin, int Cout, int k) {
+  return nq_head_supported(Cout, k) && Cin * k * k + 1 <= 512 && (int64_t)Cin * 400 * 4 <= 64 * 1024;
 }
 
 inline int wgrad_ni(int mi, int k) { return k == 1 ? 2 : (mi <= 3 ? 6 : (mi <= 6 ? 4 : 3)); }
@@ -168,6 +185,7 @@ int nq_weight_layouts(const float* w, float* wt_fwd, float* wt_bwd, int Cout, in
 
 int64_t nq_conv_forward_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
   if (!ks_ok(k) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  if (nq_head_supported(Cout, k) || nq_head_supported(Cin, k)) return 0;
   int ns = pick_nsplit(B, Cin, H, W, Cout, k);
   return ns > 1 ? (int64_t)ns * B * Cout * H * W : 0;
 }
@@ -185,6 +203,13 @@ int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y
   nq_conv_operand_dims(Cin, Cout, k, &need_rows, &need_ld);
   if (krows < need_rows || ld < need_ld || (ld & 3)) return NQ_ERR_INVALID;
   if (B > 65535) return NQ_ERR_UNSUPPORTED;
+  hipStream_t st0 = nq_s(stream);
+  // <= 4 output channels (the decoder head) / <= 4 input channels (its data gradient): HBM-bound vector kernels
+  if (use_head_fwd(Cout, k, epilogue, in_gelu))
+    return nq_head_forward(x, wt, ld, bias, y, B, Cin, H, W, Cout, k, epilogue, st0);
+  if (use_head_dgrad(Cin, k, epilogue, in_gelu, bias))
+    return nq_head_dgrad(x, wt, ld, epilogue == NQ_EPI_DGRAD_GELU ? zprev : nullptr, y, B, Cout, H, W, Cin, k,
+                         epilogue == NQ_EPI_DGRAD_GELU ? r : 1, st0);
   const int mi = pick_mi_fwd(Cout);
   const int ns = pick_nsplit(B, Cin, H, W, Cout, k);
   if (ns > 1 && !ws) return NQ_ERR_INVALID;
@@ -203,13 +228,16 @@ int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y
 int64_t nq_conv_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
   if (!ks_ok(k) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
   WgradPlan p = plan_wgrad(B, Cin, H, W, Cout, k);
-  return (int64_t)p.nsplit * p.co_pad * ((int64_t)p.n_pad + 1);
+  int64_t need = (int64_t)p.nsplit * p.co_pad * ((int64_t)p.n_pad + 1);
+  if (use_head_wgrad(Cin, Cout, k)) need = std::max<int64_t>(need, nq_head_wgrad_ws_floats(B, Cin, H, W, Cout, k));
+  return need;
 }
 
 int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                   int k, int x_gelu, nq_stream_t stream) {
   if (!x || !dy || !dw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
   if (!ks_ok(k)) return NQ_ERR_UNSUPPORTED;
+  if (use_head_wgrad(Cin, Cout, k)) return nq_head_wgrad(x, dy, dw, db, ws, B, Cin, H, W, Cout, k, x_gelu, nq_s(stream));
   WgradPlan p = plan_wgrad(B, Cin, H, W, Cout, k);
   float* slab = ws;
   float* slab_db = ws + (int64_t)p.nsplit * p.co_pad * p.n_pad;

@@ -1,0 +1,342 @@
+// Vector (VALU) kernels for the decoder's head convolution: C_in -> C_out <= 4 channels, 3x3 or 5x5 or 1x1, over the
+// full-resolution image (HNeRV/NeRV head_layer: 37|24 -> 3, k=3, 640x1280; reference models/HNeRV.py:42, :63-64).
+//
+// With 3 output channels a GEMM tile is >80 % padding, and the op is HBM-bound anyway (arithmetic intensity
+// 2*3*9 = 54 flop per 4-byte input element, ~13 flop/B << the 19.7 flop/B fp32 ridge): forward, data gradient and
+// weight gradient each read or write the 242 MB activation tensor once.  So these are streaming kernels:
+//   head_fwd   : thread = 4 consecutive pixels, input patch staged in LDS per 4-channel chunk, weights via
+//                scalar loads, fused bias + tanh*0.5+0.5 (OutImg, models/_layers.py:10-16)
+//   head_dgrad : thread = 4 pixels, the C_out x k x (4+k-1) neighbourhood of dY lives in registers, loop over C_in,
+//                fused gelu'(z) and PixelUnshuffle store (same contract as NQ_EPI_DGRAD_GELU)
+//   head_wgrad : thread = one (ci,kh,kw); LDS strides chosen so bank(n) = n mod 32; dY values are wave-uniform
+//                scalar loads; per-workgroup partial sums -> fixed-order reduction (deterministic)
+// Roofline: HBM (8 TB/s spec / 6.3 TB/s achievable); algorithmic bytes = 4*B*H*W*(C_in + C_out) per launch
+// (+ the same again for z in head_dgrad).
+#include "nq_common.h"
+
+namespace {
+
+constexpr int MAXCO = 4;
+
+__device__ __forceinline__ float gelu_grad_h(float v) {
+  float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int KS>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wt, int ld,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int Cin,
+                                                       int H, int W, int CO, int epi, int tiles_x) {
+  constexpr int KK = KS * KS, PAD = KS / 2;
+  constexpr int TH = 16, TW = 64, CCH = 4;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int PWS = (PW + 3) / 4 * 4;  // 16-byte aligned rows
+  __shared__ __attribute__((aligned(16))) float patch[CCH * PH * PWS];
+
+  const int tid = threadIdx.x;
+  const int row = tid >> 4, c4 = (tid & 15) * 4;
+  const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+  const int x0 = tile_x * TW, y0 = tile_y * TH, b = blockIdx.y;
+  const int64_t HW = (int64_t)H * W;
+  const float* __restrict__ xb = x + (int64_t)b * Cin * HW;
+
+  float acc[MAXCO][4];
+#pragma unroll
+  for (int co = 0; co < MAXCO; ++co)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
+
+  for (int c0 = 0; c0 < Cin; c0 += CCH) {
+    __syncthreads();
+    for (int e = tid; e < CCH * PH * PW; e += 256) {
+      int ci = e / (PH * PW), rem = e - ci * (PH * PW);
+      int r = rem / PW, c = rem - r * PW;
+      int gy = y0 - PAD + r, gx = x0 - PAD + c, cig = c0 + ci;
+      float v = 0.f;
+      if (cig < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) v = xb[(int64_t)cig * HW + (int64_t)gy * W + gx];
+      patch[(ci * PH + r) * PWS + c] = v;
+    }
+    __syncthreads();
+    const int cmax = min(CCH, Cin - c0);
+    for (int ci = 0; ci < cmax; ++ci) {
+      const float* __restrict__ wc = wt + (int64_t)(c0 + ci) * KK * ld;  // wt[(ci*KK + tap)*ld + co]
+#pragma unroll
+      for (int kh = 0; kh < KS; ++kh) {
+        float in[4 + KS - 1];
+        const float* pr = patch + (ci * PH + row + kh) * PWS + c4;
+#pragma unroll
+        for (int j = 0; j < 4 + KS - 1; ++j) in[j] = pr[j];
+#pragma unroll
+        for (int co = 0; co < MAXCO; ++co) {
+          if (co < CO) {
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+              const float wv = wc[(kh * KS + kw) * ld + co];  // wave-uniform -> scalar load
+#pragma unroll
+              for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(wv, in[p + kw], acc[co][p]);
+            }
+          }
+        }
+      }
+    }
+  }
+  const int gy = y0 + row;
+  if (gy >= H) return;
+#pragma unroll
+  for (int co = 0; co < MAXCO; ++co) {
+    if (co >= CO) break;
+    const float bv = bias ? bias[co] : 0.f;
+    float* __restrict__ yo = y + ((int64_t)b * CO + co) * HW + (int64_t)gy * W + x0 + c4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      if (x0 + c4 + p < W) {
+        float v = acc[co][p] + bv;
+        yo[p] = (epi == NQ_EPI_TANH) ? tanhf(v) * 0.5f + 0.5f : v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ data gradient
+template <int KS>
+__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wt, int ld,
+                                                         const float* __restrict__ zprev, float* __restrict__ out,
+                                                         int Cin, int H, int W, int CO, int r, int tiles_x) {
+  // NB naming follows the data-gradient use: "CO" (<= 4) = channels of the INPUT dy, "Cin" = channels of the OUTPUT;
+  // wt[(co*KK + tap)*ld + ci] is the (already tap-flipped) wt_bwd operand of nq_weight_layouts.
+  constexpr int KK = KS * KS, PAD = KS / 2;
+  constexpr int TH = 16, TW = 64;
+  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+  constexpr int PWS = (PW + 3) / 4 * 4;
+  __shared__ __attribute__((aligned(16))) float patch[MAXCO * PH * PWS];
+
+  const int tid = threadIdx.x;
+  const int row = tid >> 4, c4 = (tid & 15) * 4;
+  const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+  const int x0 = tile_x * TW, y0 = tile_y * TH, b = blockIdx.y;
+  const int64_t HW = (int64_t)H * W;
+  const float* __restrict__ dyb = dy + (int64_t)b * CO * HW;
+
+  for (int e = tid; e < CO * PH * PW; e += 256) {
+    int co = e / (PH * PW), rem = e - co * (PH * PW);
+    int rr = rem / PW, c = rem - rr * PW;
+    int gy = y0 - PAD + rr, gx = x0 - PAD + c;
+    float v = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = dyb[(int64_t)co * HW + (int64_t)gy * W + gx];
+    patch[(co * PH + rr) * PWS + c] = v;
+  }
+  __syncthreads();
+  // the thread's dY neighbourhood: CO x KS rows x (4+KS-1) columns, kept in registers for the whole C_in loop
+  float nb[MAXCO][KS][4 + KS - 1];
+#pragma unroll
+  for (int co = 0; co < MAXCO; ++co)
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+      for (int j = 0; j < 4 + KS - 1; ++j) nb[co][kh][j] = (co < CO) ? patch[(co * PH + row + kh) * PWS + c4 + j] : 0.f;
+
+  const int gy = y0 + row, gx0 = x0 + c4;
+  if (gy >= H || gx0 >= W) return;
+  const bool full = (gx0 + 3 < W);
+  for (int ci = 0; ci < Cin; ++ci) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co) {
+      if (co < CO) {
+        const float* __restrict__ wc = wt + (int64_t)co * KK * ld + ci;
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) {
+            const float wv = wc[(kh * KS + kw) * ld];  // wave-uniform -> scalar load
+#pragma unroll
+            for (int p = 0; p < 4; ++p) acc[p] = fmaf(wv, nb[co][kh][p + kw], acc[p]);
+          }
+      }
+    }
+    const int64_t zi = ((int64_t)b * Cin + ci) * HW + (int64_t)gy * W + gx0;
+    if (zprev) {
+      if (full && (W & 3) == 0) {
+        const float4 zv = *reinterpret_cast<const float4*>(zprev + zi);
+        acc[0] *= gelu_grad_h(zv.x); acc[1] *= gelu_grad_h(zv.y); acc[2] *= gelu_grad_h(zv.z); acc[3] *= gelu_grad_h(zv.w);
+      } else {
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+          if (gx0 + p < W) acc[p] *= gelu_grad_h(zprev[zi + p]);
+      }
+    }
+    if (r == 1) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (gx0 + p < W) out[zi + p] = acc[p];
+    } else if (r == 2 && full && (W & 3) == 0 && (H & 1) == 0) {
+      // un-shuffle: channel ci*4 + (y%2)*2 + x%2 at (y/2, x/2): pixels {0,2} -> plane j=0, {1,3} -> plane j=1
+      const int Ho = H >> 1, Wo = W >> 1;
+      const int64_t base = ((((int64_t)b * Cin + ci) * 4 + (gy & 1) * 2) * Ho + (gy >> 1)) * (int64_t)Wo + (gx0 >> 1);
+      *reinterpret_cast<float2*>(out + base) = make_float2(acc[0], acc[2]);
+      *reinterpret_cast<float2*>(out + base + (int64_t)Ho * Wo) = make_float2(acc[1], acc[3]);
+    } else {
+      const int Ho = H / r, Wo = W / r, rr2 = r * r;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int gx = gx0 + p;
+        if (gx < W) {
+          const int yq = gy / r, xq = gx / r;
+          const int ch = ci * rr2 + (gy - yq * r) * r + (gx - xq * r);
+          out[(((int64_t)b * Cin * rr2 + ch) * Ho + yq) * (int64_t)Wo + xq] = acc[p];
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+template <int KS>
+__global__ __launch_bounds__(512) void head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         float* __restrict__ part, int Cin, int H, int W, int CO,
+                                                         int tiles_x, int tiles_per_frame, int N, int x_gelu) {
+  constexpr int KK = KS * KS, PAD = KS / 2;
+  constexpr int TH = 8, TW = 32;
+  constexpr int PH = TH + KS - 1;
+  constexpr int PWS = [] {  // >= TW+KS-1, == KS (mod 32)
+    int v = TW + KS - 1;
+    while (v % 32 != KS % 32) ++v;
+    return v;
+  }();
+  constexpr int PS = [] {  // >= PH*PWS, == KK (mod 32)
+    int v = PH * PWS;
+    while (v % 32 != KK % 32) ++v;
+    return v;
+  }();
+  extern __shared__ __attribute__((aligned(16))) float xl[];  // [Cin][PS]
+
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int tile = blockIdx.x % tiles_per_frame, b = blockIdx.x / tiles_per_frame;
+  const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+  const int x0 = tile_x * TW, y0 = tile_y * TH;
+  const int64_t HW = (int64_t)H * W;
+  const float* __restrict__ xb = x + (int64_t)b * Cin * HW;
+
+  for (int e = tid; e < Cin * PH * (TW + KS - 1); e += nthr) {
+    int ci = e / (PH * (TW + KS - 1)), rem = e - ci * (PH * (TW + KS - 1));
+    int r = rem / (TW + KS - 1), c = rem - r * (TW + KS - 1);
+    int gy = y0 - PAD + r, gx = x0 - PAD + c;
+    float v = 0.f;
+    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+      v = xb[(int64_t)ci * HW + (int64_t)gy * W + gx];
+      if (x_gelu) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+    }
+    xl[ci * PS + r * PWS + c] = v;
+  }
+  __syncthreads();
+
+  // thread n = (ci, kh, kw); threads >= N idle (n == N also produces the bias gradient from a virtual all-ones input)
+  const int n = tid;
+  const bool is_w = n < N, is_b = (n == N);
+  int base = 0;
+  if (is_w) {
+    int ci = n / KK, rem = n - ci * KK, kh = rem / KS, kw = rem - kh * KS;
+    base = ci * PS + kh * PWS + kw;
+  }
+  float acc[MAXCO] = {0.f, 0.f, 0.f, 0.f};
+  const int rows = min(TH, H - y0), cols = min(TW, W - x0);
+  for (int py = 0; py < rows; ++py) {
+    const float* __restrict__ dyr = dy + (int64_t)b * CO * HW + (int64_t)(y0 + py) * W + x0;  // + co*HW, wave-uniform
+    for (int px = 0; px < cols; ++px) {
+      const float xv = is_w ? xl[base + py * PWS + px] : (is_b ? 1.f : 0.f);
+#pragma unroll
+      for (int co = 0; co < MAXCO; ++co)
+        if (co < CO) acc[co] = fmaf(dyr[(int64_t)co * HW + px], xv, acc[co]);
+    }
+  }
+  if (n <= N) {
+    float* __restrict__ po = part + (int64_t)blockIdx.x * MAXCO * (N + 1);
+#pragma unroll
+    for (int co = 0; co < MAXCO; ++co)
+      if (co < CO) po[co * (N + 1) + n] = acc[co];
+  }
+}
+
+__global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                                float* __restrict__ db, int CO, int N, int nparts) {
+  // one workgroup per output (co, n): fixed-order strided partial sums + block reduction -> deterministic
+  __shared__ float red[16];
+  const int co = blockIdx.x / (N + 1), n = blockIdx.x - co * (N + 1);
+  float acc = 0.f;
+  for (int p = threadIdx.x; p < nparts; p += 256) acc += part[(int64_t)p * MAXCO * (N + 1) + co * (N + 1) + n];
+  float s = nq_block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    if (n < N)
+      dw[(int64_t)co * N + n] = s;
+    else if (db)
+      db[co] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Selection rule shared with conv.hip: the vector path serves C_out <= 4.
+int nq_head_supported(int Cout, int k) { return Cout <= MAXCO && (k == 1 || k == 3 || k == 5); }
+
+int nq_head_forward(const float* x, const float* wt, int ld, const float* bias, float* y, int B, int Cin, int H, int W,
+                    int Cout, int k, int epi, hipStream_t st) {
+  const int tiles_x = (W + 63) / 64, tiles = tiles_x * ((H + 15) / 16);
+  dim3 g((unsigned)tiles, (unsigned)B), blk(256);
+  switch (k) {
+    case 1: hipLaunchKernelGGL(head_fwd_kernel<1>, g, blk, 0, st, x, wt, ld, bias, y, Cin, H, W, Cout, epi, tiles_x); break;
+    case 3: hipLaunchKernelGGL(head_fwd_kernel<3>, g, blk, 0, st, x, wt, ld, bias, y, Cin, H, W, Cout, epi, tiles_x); break;
+    default: hipLaunchKernelGGL(head_fwd_kernel<5>, g, blk, 0, st, x, wt, ld, bias, y, Cin, H, W, Cout, epi, tiles_x); break;
+  }
+  return nq_launch_status();
+}
+
+// dy (B,Cout,H,W) -> out = d/dx (B,Cin,H,W) [* gelu'(zprev)] stored PixelUnshuffle(r)-ed
+int nq_head_dgrad(const float* dy, const float* wt, int ld, const float* zprev, float* out, int B, int Cin, int H, int W,
+                  int Cout, int k, int r, hipStream_t st) {
+  const int tiles_x = (W + 63) / 64, tiles = tiles_x * ((H + 15) / 16);
+  dim3 g((unsigned)tiles, (unsigned)B), blk(256);
+  switch (k) {
+    case 1: hipLaunchKernelGGL(head_dgrad_kernel<1>, g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, tiles_x); break;
+    case 3: hipLaunchKernelGGL(head_dgrad_kernel<3>, g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, tiles_x); break;
+    default: hipLaunchKernelGGL(head_dgrad_kernel<5>, g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, tiles_x); break;
+  }
+  return nq_launch_status();
+}
+
+int64_t nq_head_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
+  const int64_t tiles = (int64_t)((W + 31) / 32) * ((H + 7) / 8) * B;
+  return tiles * MAXCO * ((int64_t)Cin * k * k + 1);
+}
+
+int nq_head_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+                  int k, int x_gelu, hipStream_t st) {
+  const int KK = k * k, N = Cin * KK;
+  int nthr = ((N + 1) + 63) / 64 * 64;
+  if (nthr > 512) return NQ_ERR_UNSUPPORTED;
+  const int tiles_x = (W + 31) / 32, tiles_per_frame = tiles_x * ((H + 7) / 8);
+  const int nparts = tiles_per_frame * B;
+  // LDS: [Cin][PS]; PS depends on k (see kernel)
+  auto ps_of = [](int ks) {
+    int pws = 32 + ks - 1;
+    while (pws % 32 != ks % 32) ++pws;
+    int ps = (8 + ks - 1) * pws;
+    while (ps % 32 != (ks * ks) % 32) ++ps;
+    return ps;
+  };
+  size_t lds = (size_t)Cin * ps_of(k) * sizeof(float);
+  if (lds > 64 * 1024) return NQ_ERR_UNSUPPORTED;
+  dim3 g((unsigned)nparts), blk((unsigned)nthr);
+  switch (k) {
+    case 1: hipLaunchKernelGGL(head_wgrad_kernel<1>, g, blk, lds, st, x, dy, ws, Cin, H, W, Cout, tiles_x, tiles_per_frame, N, x_gelu); break;
+    case 3: hipLaunchKernelGGL(head_wgrad_kernel<3>, g, blk, lds, st, x, dy, ws, Cin, H, W, Cout, tiles_x, tiles_per_frame, N, x_gelu); break;
+    default: hipLaunchKernelGGL(head_wgrad_kernel<5>, g, blk, lds, st, x, dy, ws, Cin, H, W, Cout, tiles_x, tiles_per_frame, N, x_gelu); break;
+  }
+  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((unsigned)(Cout * (N + 1))), dim3(256), 0, st, ws, dw, db, Cout, N, nparts);
+  return nq_launch_status();
+}
+
+}  // extern "C"
