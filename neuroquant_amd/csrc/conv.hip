@@ -94,7 +94,8 @@ inline WgradPlan plan_wgrad(int B, int Cin, int H, int W, int Cout, int k) {
   }
   int tiles = (p.co_pad / (16 * p.mi)) * (p.n_pad / (64 * p.ni));
   int nseg = ((W + 31) / 32) * H * B;
-  int ns = (768 + tiles - 1) / tiles;
+  // one full wave of workgroups: 256 CUs x 2 resident workgroups (the kernels sit at 170-230 VGPRs), no ragged tail
+  int ns = 512 / tiles;
   if (ns > nseg) ns = nseg;
   if (ns > 256) ns = 256;
   if (ns < 1) ns = 1;

@@ -24,6 +24,7 @@
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef f32x4 f32x4_u __attribute__((aligned(4)));  // 16-byte global load from a 4-byte aligned address
 
 struct WgradArgs {
   const float* x;
@@ -60,14 +61,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int MT = 16 * MI, NT = 64 * NI;
   constexpr int CIT = (NT + KK - 2) / KK + 1;  // max input channels spanned by an n-tile
   constexpr int DZ_FLOATS = MT * LDP;
-  constexpr int XE = CIT * KS * (SEG + KS - 1);  // x elements staged per segment
-  constexpr int XPT = (XE + 255) / 256;
-  constexpr int DE = MT * SEG;
-  constexpr int DPT = (DE + 255) / 256;
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* const dzl = smem;
-  float* const xl = smem + DZ_FLOATS;
+  constexpr int BUF_FLOATS = DZ_FLOATS + CIT * PSX;  // one staging buffer: dY tile + x rows
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
@@ -101,62 +97,105 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   const int seg_lo = (int)(((int64_t)a.nseg * split) / a.nsplit);
   const int seg_hi = (int)(((int64_t)a.nseg * (split + 1)) / a.nsplit);
 
-  float dv[DPT], xv[XPT];
+  // ---- staging plan: 16-byte global loads, per-thread invariants hoisted by hand (a dozen VGPRs) -------------
+  // dY tile: row = drow0 + 32*i (i < DROWS), float4 index dq within the 32-pixel row
+  // x rows : slot e = tid + 256*i -> (row = e / Q, q = e % Q), row = (ci_l, r); 4-byte aligned 16-byte loads
+  constexpr int RW = SEG + KS - 1;
+  constexpr int Q = (RW + 3) / 4;
+  constexpr int XF = CIT * KS * Q;
+  constexpr int XPT4 = (XF + 255) / 256;
+  constexpr int DROWS = (MT + 31) / 32;
+  const int dq = tid & 7, drow0 = tid >> 3;
+  const int d_off0 = (co0 + drow0) * (int)HW + 4 * dq;  // host guarantees Cout*H*W < 2^31
+  int xoff[XPT4], xlds[XPT4], xrc[XPT4];                // xrc = r * 4096 + 4q   (both >= 0)
+#pragma unroll
+  for (int i = 0; i < XPT4; ++i) {
+    const int e = tid + i * 256;
+    const int row = e / Q, q = e - row * Q;
+    const int ci_l = row / KS, r = row - ci_l * KS;
+    const bool ok = (e < XF) && (ci0 + ci_l < Cin);
+    xoff[i] = (ci0 + ci_l) * (int)HW + (r - PAD) * W + 4 * q - PAD;
+    xlds[i] = ok ? ci_l * PSX + r * PWS + 4 * q : -1;
+    xrc[i] = r * 4096 + 4 * q;
+  }
+  f32x4 dv[DROWS], xv[XPT4];
   auto load_seg = [&](int seg) {
     const int xs = seg % a.segs_x;
     const int by = seg / a.segs_x;
     const int y = by % H, b = by / H;
     const int x0 = xs * SEG;
-    // keep the per-element index math inside the loop (recomputed per segment, ~10 VALU each) instead of letting
-    // LICM hoist ~100 VGPRs of invariants across the MFMA loop
-    int t = tid;
-    asm volatile("" : "+v"(t));
+    const float* __restrict__ dyp = a.dy + (int64_t)b * Cout * HW + (int64_t)y * W + x0;
+    const float* __restrict__ xp = a.x + (int64_t)b * Cin * HW + (int64_t)y * W + x0;
+    const bool seg_full = (x0 + SEG <= W);
 #pragma unroll
-    for (int i = 0; i < DPT; ++i) {
-      int e = t + i * 256;
-      int co = e / SEG, px = e - co * SEG;
-      int gco = co0 + co, gx = x0 + px;
-      bool ok = (e < DE) && gco < Cout && gx < W;
-      dv[i] = ok ? a.dy[((int64_t)b * Cout + gco) * HW + (int64_t)y * W + gx] : 0.f;
+    for (int i = 0; i < DROWS; ++i) {
+      const int row = drow0 + 32 * i;
+      const bool ok = (row < MT) && (co0 + row < Cout);
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (ok) {
+        const float* p = dyp + d_off0 + i * 32 * (int)HW;
+        if (seg_full) {
+          v = *reinterpret_cast<const f32x4_u*>(p);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (x0 + 4 * dq + j < W) v[j] = p[j];
+        }
+      }
+      dv[i] = v;
     }
 #pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-      int e = t + i * 256;
-      int ci = e / (KS * (SEG + KS - 1)), rem = e - ci * (KS * (SEG + KS - 1));
-      int r = rem / (SEG + KS - 1), c = rem - r * (SEG + KS - 1);
-      int gci = ci0 + ci, gy = y - PAD + r, gx = x0 - PAD + c;
-      bool ok = (e < XE) && gci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      xv[i] = ok ? a.x[((int64_t)b * Cin + gci) * HW + (int64_t)gy * W + gx] : 0.f;
+    for (int i = 0; i < XPT4; ++i) {
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (xlds[i] >= 0) {
+        const int gy = y + (xrc[i] >> 12) - PAD, gx0 = x0 + (xrc[i] & 4095) - PAD;
+        if (gy >= 0 && gy < H) {
+          const float* p = xp + xoff[i];
+          if (gx0 >= 0 && gx0 + 3 < W) {
+            v = *reinterpret_cast<const f32x4_u*>(p);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (gx0 + j >= 0 && gx0 + j < W) v[j] = p[j];
+          }
+        }
+      }
+      xv[i] = v;
     }
   };
-  auto store_seg = [&]() {
-    int t = tid;
-    asm volatile("" : "+v"(t));
+  auto store_seg = [&](float* dzl, float* xl) {
 #pragma unroll
-    for (int i = 0; i < DPT; ++i) {
-      int e = t + i * 256;
-      if (e < DE) {
-        int co = e / SEG, px = e - co * SEG;
-        dzl[co * LDP + px] = dv[i];
+    for (int i = 0; i < DROWS; ++i) {
+      const int row = drow0 + 32 * i;
+      if (row < MT) {
+        float* d = dzl + row * LDP + 4 * dq;
+        d[0] = dv[i][0]; d[1] = dv[i][1]; d[2] = dv[i][2]; d[3] = dv[i][3];
       }
     }
 #pragma unroll
-    for (int i = 0; i < XPT; ++i) {
-      int e = t + i * 256;
-      if (e < XE) {
-        int ci = e / (KS * (SEG + KS - 1)), rem = e - ci * (KS * (SEG + KS - 1));
-        int r = rem / (SEG + KS - 1), c = rem - r * (SEG + KS - 1);
-        xl[ci * PSX + r * PWS + c] = a.x_gelu ? wgrad_gelu(xv[i]) : xv[i];
+    for (int i = 0; i < XPT4; ++i) {
+      if (xlds[i] >= 0) {
+        const int cc = xrc[i] & 4095;  // 4q
+        float* d = xl + xlds[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (cc + j < RW) d[j] = a.x_gelu ? wgrad_gelu(xv[i][j]) : xv[i][j];
       }
     }
   };
 
-  if (seg_lo < seg_hi) load_seg(seg_lo);
-  for (int seg = seg_lo; seg < seg_hi; ++seg) {
-    __syncthreads();  // previous segment's readers are done
-    store_seg();
+  // double-buffered LDS: MFMAs of segment s read buf[s&1] while the registers holding segment s+1 are written
+  // to buf[(s+1)&1] right after them; one barrier per segment, global loads run one segment ahead of the stores
+  if (seg_lo < seg_hi) {
+    load_seg(seg_lo);
+    store_seg(smem, smem + DZ_FLOATS);
     __syncthreads();
-    if (seg + 1 < seg_hi) load_seg(seg + 1);  // in flight under the MFMAs below
+    if (seg_lo + 1 < seg_hi) load_seg(seg_lo + 1);
+  }
+  for (int seg = seg_lo; seg < seg_hi; ++seg) {
+    const int cur = (seg - seg_lo) & 1;
+    const float* __restrict__ dzl = smem + cur * BUF_FLOATS;
+    const float* __restrict__ xl = dzl + DZ_FLOATS;
     // ---- 8 k-steps of 4 pixels, fragments software-pipelined one step ahead (see conv_igemm_impl.h) ----
     {
       float af0[MI], af1[MI], bf0[NI], bf1[NI];
@@ -194,6 +233,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
       for (int px = 0; px < SEG; ++px) sacc += dzl[tid * LDP + px];
       db_acc += sacc;
     }
+    if (seg + 1 < seg_hi) {
+      float* nb = smem + (cur ^ 1) * BUF_FLOATS;
+      store_seg(nb, nb + DZ_FLOATS);
+    }
+    __syncthreads();
+    if (seg + 2 < seg_hi) load_seg(seg + 2);
   }
 
   // ---- write the partial slab ----
@@ -218,8 +263,15 @@ template <int MI, int NI>
 int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   constexpr int MT = 16 * MI, NT = 64 * NI;
   constexpr int CIT = (NT + KK - 2) / KK + 1;
-  size_t lds = (size_t)(MT * LDP + CIT * PSX) * sizeof(float);
+  size_t lds = (size_t)2 * (MT * LDP + CIT * PSX) * sizeof(float);
   dim3 grid((unsigned)a.nsplit, (unsigned)(a.n_pad / NT), (unsigned)(a.co_pad / MT));
+  static bool attr_set = false;  // > 64 KB of dynamic LDS needs an explicit opt-in (idempotent, so a race is harmless)
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<MI, NI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return NQ_ERR_LAUNCH;
+    attr_set = true;
+  }
   hipLaunchKernelGGL((conv_wgrad_kernel<MI, NI>), grid, dim3(256), lds, st, a);
   return nq_launch_status();
 }
