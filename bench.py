@@ -151,7 +151,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(f'{dom["kernel"]}_k{dom["k"]}_{dom["cin"]}_{dom["cout"]}')
+            traffic = json.load(open(tpath)).get(f'{dom["kernel"]}_k{dom["k"]}_{dom["cin"]}_{dom["cout"]}', {}).get("bytes")
         except Exception:
             traffic = None
     roofline = dict(bound="mfma", kernel=f'{dom["kernel"]} k{dom["k"]} {dom["cin"]}->{dom["cout"]} {dom["H"]}x{dom["W"]}',
@@ -193,7 +193,13 @@ def cpu_baseline(sd, frames_u8, emb, n_iters):
     """Time the oracle's phase-2 iteration on the same HNeRV-3M weights / first 8 frames, all host cores."""
     import numpy as np
     from oracle import nq_oracle as O
-    cores = os.cpu_count() or 1
+    # the box's CPU share for one GPU is 16 cores (os.cpu_count() reports the whole 256-thread host; oversubscribing
+    # it made the oracle 10x slower), so use the affinity mask capped at 16
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     dec = O.Decoder.from_state_dict(sd, "hnerv", HNERV_3M["dec_strides"])
     qs = O.QuantStack(dec, BITS, hadamard=False)

@@ -49,7 +49,7 @@ constexpr int CI = (KS == 5) ? 4 : (KS == 3) ? 8 : 16;  // input channels per sl
 constexpr int CIQ = CI / 4;                              // channels per lane group
 constexpr int TH = 4, TW = 32;
 constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
-constexpr int WROWS = CI * KS;  // weight rows per slice
+constexpr int WROWS1 = CI * KS;  // weight rows per kernel row kh
 
 constexpr int pad_to_mod32(int v, int mult, int want) {  // smallest v' >= v with (mult*v') % 32 == want
   while ((mult * v) % 32 != want) ++v;
@@ -77,9 +77,15 @@ __device__ __forceinline__ float gelu_grad_exact(float v) {
   return cdf + v * pdf;
 }
 
+// Kernel rows per slice: narrow channel tiles (MI <= 4: the data gradients 148->44, 176->53, 848->64) would otherwise
+// run only 6*MI MFMAs between barriers; they take a whole channel group (all KS kernel rows) per slice instead.
+constexpr int khs_for(int mi) { return (mi <= 4) ? KS : 1; }
+
 template <int MI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_igemm_kernel(ConvArgs a) {
   constexpr int MT = 16 * MI;
+  constexpr int KHS = khs_for(MI);
+  constexpr int WROWS = WROWS1 * KHS;
   // (CIQ*KS*LDW) % 32 == 16 and LDW % 4 == 0
   constexpr int LDW = [] {
     int v = MT;
@@ -138,8 +144,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int f = tid + i * 256;                                                                        \
     if (i + 1 < WPT || f < WF4) {                                                                 \
       int row = f / (MT / 4), c4 = f - row * (MT / 4);                                            \
-      int ci = row / KS, kw = row - ci * KS;                                                      \
-      int grow = (((CG) * CI + ci) * KS + (KH)) * KS + kw;                                        \
+      int khl = row / WROWS1, r1 = row - khl * WROWS1;                                            \
+      int ci = r1 / KS, kw = r1 - ci * KS;                                                        \
+      int grow = (((CG) * CI + ci) * KS + (KH) + khl) * KS + kw;                                  \
       wv[i] = *reinterpret_cast<const f32x4*>(wt + (int64_t)grow * ld + c4 * 4);                 \
     }                                                                                             \
   }
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // split-K: this workgroup covers channel groups [cg_lo, cg_hi)
   const int cg_lo = (int)(((int64_t)a.ncg * split) / a.nsplit);
   const int cg_hi = (int)(((int64_t)a.ncg * (split + 1)) / a.nsplit);
-  const int nslices = (cg_hi - cg_lo) * KS;
+  const int nslices = (cg_hi - cg_lo) * (KS / KHS);
   NQ_LOAD_PATCH(cg_lo)
   NQ_LOAD_W(cg_lo, 0)
   NQ_STORE_PATCH(patch0)
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   int cg = cg_lo, kh = 0;
   for (int s = 0; s < nslices; ++s) {
-    int ncg_ = cg, nkh = kh + 1;
+    int ncg_ = cg, nkh = kh + KHS;
     if (nkh == KS) {
       nkh = 0;
       ncg_ = cg + 1;
@@ -195,14 +202,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // (hipcc otherwise funnels every A fragment through one register pair and exposes the LDS latency
     // after every 4 MFMAs); sched_barrier pins "reads of the next step, then MFMAs of this step".
     {
-      constexpr int STEPS = CIQ * KS;
+      constexpr int STEPS = KHS * CIQ * KS;
       float af0[MI], af1[MI], bf0[2], bf1[2];
 #define NQ_LDFRAG(AF, BF, ST)                                                                         \
   {                                                                                                   \
-    constexpr int t_ = (ST) / KS, kw_ = (ST)-t_ * KS;                                                 \
-    BF[0] = pb[t_ * PS + kw_];                                                                        \
-    BF[1] = pb[t_ * PS + kw_ + 16];                                                                   \
-    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) AF[mi] = wb[(t_ * KS + kw_) * LDW + mi * 16];   \
+    constexpr int khl_ = (ST) / (CIQ * KS), s1_ = (ST)-khl_ * (CIQ * KS);                             \
+    constexpr int t_ = s1_ / KS, kw_ = s1_ - t_ * KS;                                                 \
+    BF[0] = pb[t_ * PS + khl_ * PW + kw_];                                                            \
+    BF[1] = pb[t_ * PS + khl_ * PW + kw_ + 16];                                                       \
+    _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                                 \
+        AF[mi] = wb[(khl_ * WROWS1 + t_ * KS + kw_) * LDW + mi * 16];                                 \
   }
 #define NQ_MFMAS(AF, BF)                                                                              \
   _Pragma("unroll") for (int mi = 0; mi < MI; ++mi) {                                                 \
@@ -400,7 +409,14 @@ int launch_igemm(const ConvArgs& a, int tiles, int co_tiles, hipStream_t st) {
     while ((CIQ * KS * v) % 32 != 16 || (v % 4) != 0) ++v;
     return v;
   }();
-  size_t lds = (size_t)(2 * PATCH_FLOATS + 2 * WROWS * LDW) * sizeof(float);
+  size_t lds = (size_t)(2 * PATCH_FLOATS + 2 * WROWS1 * khs_for(MI) * LDW) * sizeof(float);
+  static bool attr_set = false;  // > 64 KB of dynamic LDS needs an explicit opt-in (idempotent)
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return NQ_ERR_LAUNCH;
+    attr_set = true;
+  }
   hipLaunchKernelGGL(conv_igemm_kernel<MI>, dim3((unsigned)tiles, (unsigned)co_tiles, (unsigned)(a.B * a.nsplit)), dim3(256), lds, st,
                      a);
   return nq_launch_status();
