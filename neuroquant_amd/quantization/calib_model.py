@@ -15,6 +15,7 @@ host synchronisation per iteration (the reference's decode sync and 500-step flo
 syncs it had; the log sync is kept, the decode sync is not).
 """
 import logging
+import os
 
 import torch
 import torch.nn as nn
@@ -146,7 +147,7 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
             L.m.bias_quantizer(L.bias)
     done = 0
     dp = torch.distributed.is_available() and torch.distributed.is_initialized() and \
-        torch.distributed.get_world_size() > 1
+        (torch.distributed.get_world_size() > 1 or bool(os.environ.get("NQ_DP_REHEARSAL")))
 
     def run(epochs, params, opt_lr, max_count, ada):
         nonlocal done

@@ -99,20 +99,33 @@ class CacheLoader:
     every global batch (data-parallel sharding); the order comes from a CPU generator seeded identically
     on every rank, or from a recorded `order` array (epochs, batches, B)."""
 
-    def __init__(self, cache: FrameCache, indices, batch_size, seed=903, rank=0, world=1, order=None):
+    def __init__(self, cache: FrameCache, indices, batch_size, seed=903, rank=0, world=1, order=None,
+                 epoch_batches=None):
         assert batch_size % world == 0, "global batch must divide across ranks"
         self.cache, self.indices, self.bs = cache, list(indices), batch_size
         self.gen = torch.Generator().manual_seed(seed)
         self.rank, self.world, self.order, self.epoch = rank, world, order, 0
         self.n_total = len(cache)
+        # epoch_batches: report/yield this many batches per "epoch" by chaining shuffled passes (benchmarks that need
+        # an exact number of iterations independent of the frame count)
+        self.epoch_batches = epoch_batches
 
     def __len__(self):
-        return len(self.indices) // self.bs if self.order is None else self.order.shape[1]
+        if self.order is not None:
+            return self.order.shape[1]
+        return self.epoch_batches or len(self.indices) // self.bs
+
+    def _one_pass(self):
+        per_pass = len(self.indices) // self.bs
+        perm = torch.randperm(len(self.indices), generator=self.gen)
+        return torch.tensor(self.indices)[perm][: per_pass * self.bs].view(per_pass, self.bs)
 
     def __iter__(self):
         if self.order is None:
-            perm = torch.randperm(len(self.indices), generator=self.gen)
-            sel = torch.tensor(self.indices)[perm][: len(self) * self.bs].view(len(self), self.bs)
+            sel = self._one_pass()
+            while self.epoch_batches and sel.shape[0] < self.epoch_batches:
+                sel = torch.cat([sel, self._one_pass()])
+            sel = sel[: len(self)]
         else:
             sel = torch.as_tensor(self.order[self.epoch % self.order.shape[0]], dtype=torch.int64)
         self.epoch += 1
@@ -128,8 +141,10 @@ def allreduce_mean_(tensors, group=None):
     1/world (each rank's loss is a local mean).  RCCL on GPU tensors, gloo on CPU tensors.  No-op when
     torch.distributed is not initialised or world == 1."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return tensors
+    if dist.get_world_size(group) == 1 and not os.environ.get("NQ_DP_REHEARSAL"):
+        return tensors   # (NQ_DP_REHEARSAL=1 runs the collective on a 1-rank group: rehearses the path on one GPU)
     flat = torch.cat([t.reshape(-1) for t in tensors])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     flat.div_(dist.get_world_size(group))
