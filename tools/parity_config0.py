@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Full-size parity run (BASELINE config 0 shape): HNeRV Bunny_1280x640_3M, 8 frames, --precision 6 5 4 5 5 6 6,
+batch 2, iters_w = 50 (0 phase-1 epochs + 12 phase-2 epochs = 48 iterations), GPU engine vs the CPU oracle on the
+SAME checkpoint, frames, embeddings and batch order.
+
+The reference's epoch300 checkpoints are not available offline, and a random-init decoder gives 11.5 dB
+whatever the quantisation, so the checkpoint is produced here: a short FP32 fit of the model on 8 synthetic frames
+with plain PyTorch on the GPU (plumbing, not part of the measured path).  Prints per-iteration loss agreement and
+PSNR (FP / quant w/o opt / quant w/ opt) for both sides; exit code 1 if the final PSNRs differ by >= 0.02 dB.
+
+    python tools/parity_config0.py [--train-steps 600] [--cpu-threads 16]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from bench import BITS, HNERV_3M  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--train-steps", type=int, default=600)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--iters", type=int, default=50)
+    args = ap.parse_args()
+
+    from neuroquant_amd import ops
+    from neuroquant_amd.models import HNeRV
+    from neuroquant_amd.quantization import QuantModel, model_reconstruction
+    from neuroquant_amd.utils import CacheLoader, FrameCache, synthetic_frames
+    from oracle import nq_oracle as O
+
+    dev = torch.device("cuda", 0)
+    n, B = 8, 2
+    torch.manual_seed(903)
+    frames_u8 = synthetic_frames(n, 640, 1280, seed=903, device=dev)
+    frames = frames_u8.float() / 255.0
+    model = HNeRV(HNERV_3M).to(dev)
+
+    # ---- FP32 fit (plain PyTorch / MIOpen; only to obtain a non-trivial checkpoint) ----
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    t0 = time.time()
+    for step in range(args.train_steps):
+        lr = 1e-3 * 0.5 * (1 + np.cos(np.pi * step / args.train_steps))
+        for g in opt.param_groups:
+            g["lr"] = lr
+        i = step % n
+        out = torch.tanh(_decode_fp(model, model.encode(frames[i:i + 1]))) * 0.5 + 0.5
+        loss = F.mse_loss(out, frames[i:i + 1])
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    print(f"FP32 fit: {args.train_steps} steps in {time.time() - t0:.1f}s, last loss {loss.item():.5f}", flush=True)
+    model.eval()
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        emb = torch.cat([model.encode(frames[i:i + 1]) for i in range(n)])
+
+    g = torch.Generator().manual_seed(903)
+    n_ep = args.iters // (n // B)
+    order = torch.stack([torch.randperm(n, generator=g).view(n // B, B) for _ in range(n_ep)]).numpy()
+    flags = dict(weight=0.01, b_range=(20, 2), warmup=0.2, lr=0.003)
+
+    # ---- GPU engine ----
+    cache = FrameCache(frames_u8)
+    qnn = QuantModel(model, hadamard=False, weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
+    qnn.set_bitwidth(BITS)
+    qnn.eval()
+
+    def psnr_gpu():
+        with torch.no_grad():
+            return float(torch.cat([ops.frame_psnr(qnn(emb[i:i + 1])[0], frames[i:i + 1]) for i in range(n)]).mean())
+
+    res = {"gpu": {}, "cpu": {}}
+    qnn.set_quant_state(False)
+    res["gpu"]["fp"] = psnr_gpu()
+    qnn.set_quant_state(True)
+    res["gpu"]["q_noopt"] = psnr_gpu()
+    rec = []
+    loader = CacheLoader(cache, list(range(n)), B, order=order)
+    t0 = time.time()
+    model_reconstruction(qnn, cali_data=emb, gt=loader, arch="hnerv", batch_size=B, iters=args.iters, hadamard=False,
+                         recorder=rec, **flags)
+    torch.cuda.synchronize()
+    t_gpu = time.time() - t0
+    qnn.set_quant_state(True)
+    res["gpu"]["q_opt"] = psnr_gpu()
+    res["gpu"]["it_per_s_with_logging_sync"] = len(rec) / t_gpu
+
+    # ---- CPU oracle ----
+    torch.set_num_threads(args.cpu_threads)
+    dec = O.Decoder.from_state_dict({k: v for k, v in sd.items() if not k.startswith("encoder")}, "hnerv",
+                                    HNERV_3M["dec_strides"])
+    fr_c, emb_c = frames.cpu(), emb.cpu()
+    with torch.no_grad():
+        res["cpu"]["fp"] = float(O.psnr_per_frame(dec.forward(emb_c), fr_c).mean())
+    qs = O.QuantStack(dec, BITS, hadamard=False)
+    with torch.no_grad():
+        res["cpu"]["q_noopt"] = float(O.psnr_per_frame(qs.forward(emb_c), fr_c).mean())
+    t0 = time.time()
+    log = np.array(O.calibrate(qs, emb_c, fr_c, order, args.iters, **flags))
+    t_cpu = time.time() - t0
+    with torch.no_grad():
+        res["cpu"]["q_opt"] = float(O.psnr_per_frame(qs.forward(emb_c), fr_c).mean())
+    res["cpu"]["it_per_s"] = len(log) / t_cpu
+    rec = np.array(rec)
+    rel = np.abs(rec[:, 0] - log[:, 0]) / np.abs(log[:, 0])
+    res["iterations"] = int(len(log))
+    res["loss_rel_diff_first3"] = float(rel[:3].max())
+    res["loss_rel_diff_max"] = float(rel.max())
+    res["psnr_diff_q_opt_dB"] = abs(res["gpu"]["q_opt"] - res["cpu"]["q_opt"])
+    print(json.dumps(res, indent=1))
+    sys.exit(0 if res["psnr_diff_q_opt_dB"] < 0.02 else 1)
+
+
+def _decode_fp(model, emb):
+    """FP32 decoder forward through plain torch modules (pre-QuantModel), returning the head's pre-tanh output."""
+    x = model.decoder[0](emb)
+    for layer in model.decoder[1:]:
+        x = layer(x)
+    return model.head_layer(x)
+
+
+if __name__ == "__main__":
+    main()
