@@ -16,8 +16,6 @@ int nq_conv_splitk_finish(const float*, const float*, float*, float*, const floa
 int nq_head_supported(int, int);
 int nq_head_forward(const float*, const float*, int, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
 int nq_head_dgrad(const float*, const float*, int, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
-int64_t nq_head_wgrad_ws_floats(int, int, int, int, int, int);
-int nq_head_wgrad(const float*, const float*, float*, float*, float*, int, int, int, int, int, int, int, hipStream_t);
 int nq_conv_wgrad_k1(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
                      int, hipStream_t);
 int nq_conv_wgrad_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
@@ -64,9 +62,6 @@ inline bool use_head_fwd(int Cout, int k, int epi, int in_gelu) {
 }
 inline bool use_head_dgrad(int Cin, int k, int epi, int in_gelu, const float* bias) {
   return nq_head_supported(Cin, k) && (epi == NQ_EPI_PLAIN || epi == NQ_EPI_DGRAD_GELU) && !in_gelu && !bias;
-}
-inline bool use_head_wgrad(int Cin, int Cout, int k) {
-  return nq_head_supported(Cout, k) && Cin * k * k + 1 <= 512 && (int64_t)Cin * 400 * 4 <= 64 * 1024;
 }
 
 inline int wgrad_ni(int mi, int k) { return k == 1 ? 2 : (mi <= 3 ? 6 : (mi <= 6 ? 4 : 3)); }
@@ -229,16 +224,13 @@ int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y
 int64_t nq_conv_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
   if (!ks_ok(k) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
   WgradPlan p = plan_wgrad(B, Cin, H, W, Cout, k);
-  int64_t need = (int64_t)p.nsplit * p.co_pad * ((int64_t)p.n_pad + 1);
-  if (use_head_wgrad(Cin, Cout, k)) need = std::max<int64_t>(need, nq_head_wgrad_ws_floats(B, Cin, H, W, Cout, k));
-  return need;
+  return (int64_t)p.nsplit * p.co_pad * ((int64_t)p.n_pad + 1);
 }
 
 int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                   int k, int x_gelu, nq_stream_t stream) {
   if (!x || !dy || !dw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
   if (!ks_ok(k)) return NQ_ERR_UNSUPPORTED;
-  if (use_head_wgrad(Cin, Cout, k)) return nq_head_wgrad(x, dy, dw, db, ws, B, Cin, H, W, Cout, k, x_gelu, nq_s(stream));
   WgradPlan p = plan_wgrad(B, Cin, H, W, Cout, k);
   float* slab = ws;
   float* slab_db = ws + (int64_t)p.nsplit * p.co_pad * p.n_pad;

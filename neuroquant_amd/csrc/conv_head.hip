@@ -2,14 +2,14 @@
 // full-resolution image (HNeRV/NeRV head_layer: 37|24 -> 3, k=3, 640x1280; reference models/HNeRV.py:42, :63-64).
 //
 // With 3 output channels a GEMM tile is >80 % padding, and the op is HBM-bound anyway (arithmetic intensity
-// 2*3*9 = 54 flop per 4-byte input element, ~13 flop/B << the 19.7 flop/B fp32 ridge): forward, data gradient and
-// weight gradient each read or write the 242 MB activation tensor once.  So these are streaming kernels:
+// 2*3*9 = 54 flop per 4-byte input element, ~13 flop/B << the 19.7 flop/B fp32 ridge): forward and data gradient
+// each read or write the 242 MB activation tensor once.  So these are streaming kernels:
 //   head_fwd   : thread = 4 consecutive pixels, input patch staged in LDS per 4-channel chunk, weights via
 //                scalar loads, fused bias + tanh*0.5+0.5 (OutImg, models/_layers.py:10-16)
 //   head_dgrad : thread = 4 pixels, the C_out x k x (4+k-1) neighbourhood of dY lives in registers, loop over C_in,
 //                fused gelu'(z) and PixelUnshuffle store (same contract as NQ_EPI_DGRAD_GELU)
-//   head_wgrad : thread = one (ci,kh,kw); LDS strides chosen so bank(n) = n mod 32; dY values are wave-uniform
-//                scalar loads; per-workgroup partial sums -> fixed-order reduction (deterministic)
+// (The weight gradient of the head stays on the MFMA split-K kernel of conv_wgrad_impl.h: a VALU variant with one
+//  thread per (ci,kh,kw) was measured slower, 0.66-0.80 ms vs 0.56 ms.)
 // Roofline: HBM (8 TB/s spec / 6.3 TB/s achievable); algorithmic bytes = 4*B*H*W*(C_in + C_out) per launch
 // (+ the same again for z in head_dgrad).
 #include "nq_common.h"
@@ -192,89 +192,6 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
   }
 }
 
-// ------------------------------------------------------------------------------------------------ weight gradient
-template <int KS>
-__global__ __launch_bounds__(512) void head_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                         float* __restrict__ part, int Cin, int H, int W, int CO,
-                                                         int tiles_x, int tiles_per_frame, int N, int x_gelu) {
-  constexpr int KK = KS * KS, PAD = KS / 2;
-  constexpr int TH = 8, TW = 32;
-  constexpr int PH = TH + KS - 1;
-  constexpr int PWS = [] {  // >= TW+KS-1, == KS (mod 32)
-    int v = TW + KS - 1;
-    while (v % 32 != KS % 32) ++v;
-    return v;
-  }();
-  constexpr int PS = [] {  // >= PH*PWS, == KK (mod 32)
-    int v = PH * PWS;
-    while (v % 32 != KK % 32) ++v;
-    return v;
-  }();
-  extern __shared__ __attribute__((aligned(16))) float xl[];  // [Cin][PS]
-
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const int tile = blockIdx.x % tiles_per_frame, b = blockIdx.x / tiles_per_frame;
-  const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-  const int x0 = tile_x * TW, y0 = tile_y * TH;
-  const int64_t HW = (int64_t)H * W;
-  const float* __restrict__ xb = x + (int64_t)b * Cin * HW;
-
-  for (int e = tid; e < Cin * PH * (TW + KS - 1); e += nthr) {
-    int ci = e / (PH * (TW + KS - 1)), rem = e - ci * (PH * (TW + KS - 1));
-    int r = rem / (TW + KS - 1), c = rem - r * (TW + KS - 1);
-    int gy = y0 - PAD + r, gx = x0 - PAD + c;
-    float v = 0.f;
-    if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-      v = xb[(int64_t)ci * HW + (int64_t)gy * W + gx];
-      if (x_gelu) v = v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-    }
-    xl[ci * PS + r * PWS + c] = v;
-  }
-  __syncthreads();
-
-  // thread n = (ci, kh, kw); threads >= N idle (n == N also produces the bias gradient from a virtual all-ones input)
-  const int n = tid;
-  const bool is_w = n < N, is_b = (n == N);
-  int base = 0;
-  if (is_w) {
-    int ci = n / KK, rem = n - ci * KK, kh = rem / KS, kw = rem - kh * KS;
-    base = ci * PS + kh * PWS + kw;
-  }
-  float acc[MAXCO] = {0.f, 0.f, 0.f, 0.f};
-  const int rows = min(TH, H - y0), cols = min(TW, W - x0);
-  for (int py = 0; py < rows; ++py) {
-    const float* __restrict__ dyr = dy + (int64_t)b * CO * HW + (int64_t)(y0 + py) * W + x0;  // + co*HW, wave-uniform
-    for (int px = 0; px < cols; ++px) {
-      const float xv = is_w ? xl[base + py * PWS + px] : (is_b ? 1.f : 0.f);
-#pragma unroll
-      for (int co = 0; co < MAXCO; ++co)
-        if (co < CO) acc[co] = fmaf(dyr[(int64_t)co * HW + px], xv, acc[co]);
-    }
-  }
-  if (n <= N) {
-    float* __restrict__ po = part + (int64_t)blockIdx.x * MAXCO * (N + 1);
-#pragma unroll
-    for (int co = 0; co < MAXCO; ++co)
-      if (co < CO) po[co * (N + 1) + n] = acc[co];
-  }
-}
-
-__global__ __launch_bounds__(256) void head_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                                float* __restrict__ db, int CO, int N, int nparts) {
-  // one workgroup per output (co, n): fixed-order strided partial sums + block reduction -> deterministic
-  __shared__ float red[16];
-  const int co = blockIdx.x / (N + 1), n = blockIdx.x - co * (N + 1);
-  float acc = 0.f;
-  for (int p = threadIdx.x; p < nparts; p += 256) acc += part[(int64_t)p * MAXCO * (N + 1) + co * (N + 1) + n];
-  float s = nq_block_sum(acc, red);
-  if (threadIdx.x == 0) {
-    if (n < N)
-      dw[(int64_t)co * N + n] = s;
-    else if (db)
-      db[co] = s;
-  }
-}
-
 }  // namespace
 
 extern "C" {
@@ -304,38 +221,6 @@ int nq_head_dgrad(const float* dy, const float* wt, int ld, const float* zprev, 
     case 3: hipLaunchKernelGGL(head_dgrad_kernel<3>, g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, tiles_x); break;
     default: hipLaunchKernelGGL(head_dgrad_kernel<5>, g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, tiles_x); break;
   }
-  return nq_launch_status();
-}
-
-int64_t nq_head_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
-  const int64_t tiles = (int64_t)((W + 31) / 32) * ((H + 7) / 8) * B;
-  return tiles * MAXCO * ((int64_t)Cin * k * k + 1);
-}
-
-int nq_head_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
-                  int k, int x_gelu, hipStream_t st) {
-  const int KK = k * k, N = Cin * KK;
-  int nthr = ((N + 1) + 63) / 64 * 64;
-  if (nthr > 512) return NQ_ERR_UNSUPPORTED;
-  const int tiles_x = (W + 31) / 32, tiles_per_frame = tiles_x * ((H + 7) / 8);
-  const int nparts = tiles_per_frame * B;
-  // LDS: [Cin][PS]; PS depends on k (see kernel)
-  auto ps_of = [](int ks) {
-    int pws = 32 + ks - 1;
-    while (pws % 32 != ks % 32) ++pws;
-    int ps = (8 + ks - 1) * pws;
-    while (ps % 32 != (ks * ks) % 32) ++ps;
-    return ps;
-  };
-  size_t lds = (size_t)Cin * ps_of(k) * sizeof(float);
-  if (lds > 64 * 1024) return NQ_ERR_UNSUPPORTED;
-  dim3 g((unsigned)nparts), blk((unsigned)nthr);
-  switch (k) {
-    case 1: hipLaunchKernelGGL(head_wgrad_kernel<1>, g, blk, lds, st, x, dy, ws, Cin, H, W, Cout, tiles_x, tiles_per_frame, N, x_gelu); break;
-    case 3: hipLaunchKernelGGL(head_wgrad_kernel<3>, g, blk, lds, st, x, dy, ws, Cin, H, W, Cout, tiles_x, tiles_per_frame, N, x_gelu); break;
-    default: hipLaunchKernelGGL(head_wgrad_kernel<5>, g, blk, lds, st, x, dy, ws, Cin, H, W, Cout, tiles_x, tiles_per_frame, N, x_gelu); break;
-  }
-  hipLaunchKernelGGL(head_wgrad_reduce_kernel, dim3((unsigned)(Cout * (N + 1))), dim3(256), 0, st, ws, dw, db, Cout, N, nparts);
   return nq_launch_status();
 }
 
