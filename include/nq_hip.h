@@ -128,6 +128,27 @@ int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y
                     int W, int Cout, int k, int krows, int ld, int r, int epilogue, int in_gelu, const float* zprev,
                     nq_stream_t stream);
 
+/* ---- "bf16x3" variant of nq_conv_forward: fp32-equivalent accuracy on the BF16 matrix pipe ------------------------
+ * Every fp32 operand is split into bf16 hi + lo and each product formed as hi*hi + hi*lo + lo*hi with fp32
+ * accumulation (v_mfma_f32_16x16x32_bf16): relative error ~2^-16 per product before accumulation, i.e. the same
+ * order as the fp32 rounding noise of these K~1000 contractions; 5.3x the fp32-MFMA rate.  k in {3,5} only.
+ *   nq_conv3_supported    : 1 when the shape is served by this path (enough workgroups, > 4 channels each side)
+ *   nq_conv3_weight_bytes : size of the pre-split operand of a (Cin -> Cout, k) convolution
+ *   nq_weight_layout3     : builds it from the OIHW weight w; transposed = 1 builds the operand of the data gradient
+ *                           (then Cin/Cout are those of the gradient convolution: Cin = w's C_out, Cout = w's C_in)
+ *   nq_conv_forward3      : same contract as nq_conv_forward (epilogues, zprev), no split-K workspace */
+int nq_conv3_supported(int B, int Cin, int H, int W, int Cout, int k);
+int64_t nq_conv3_weight_bytes(int Cin, int Cout, int k);
+int nq_weight_layout3(const float* w, void* wt3, int Cin, int Cout, int k, int transposed, nq_stream_t stream);
+int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* y, float* z, const float* zprev, int B, int Cin,
+                     int H, int W, int Cout, int k, int r, int epilogue, nq_stream_t stream);
+
+/* bf16x3 variant of nq_conv_wgrad (same contract, x_gelu not offered): */
+int nq_conv_wgrad3_supported(int B, int Cin, int H, int W, int Cout, int k);
+int64_t nq_conv_wgrad3_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
+int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+                   int k, nq_stream_t stream);
+
 /* Weight + bias gradient of the same convolution: dw (Cout,Cin,k,k), db (Cout) (db may be NULL),
  * from x (B,Cin,H,W) and dy (B,Cout,H,W).  ws: scratch of >= nq_conv_wgrad_ws_floats(...) floats.
  * x_gelu != 0: x holds pre-activations, exact GELU is applied while staging.  Deterministic (fixed split-K order). */

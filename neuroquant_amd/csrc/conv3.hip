@@ -1,0 +1,184 @@
+// C-ABI entry points of the bf16x3 convolution path (conv_igemm3_impl.h): weight pre-split/re-order + dispatch.
+#include "nq_common.h"
+
+extern "C" {
+int nq_conv_igemm3_k3(const float*, const void*, const float*, float*, float*, const float*, int, int, int, int, int, int, int,
+                      int, hipStream_t);
+int nq_conv_igemm3_k5(const float*, const void*, const float*, float*, float*, const float*, int, int, int, int, int, int, int,
+                      int, hipStream_t);
+int nq_conv3_nst_k3();
+int nq_conv3_nst_k5();
+int nq_conv_wgrad3_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, hipStream_t);
+int nq_conv_wgrad3_k5(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, hipStream_t);
+}
+
+namespace {
+
+constexpr int CC = 16;
+
+inline int pick_mi3(int Cout) {
+  int best = 1, best_pad = 1 << 30;
+  for (int mi = 5; mi >= 1; --mi) {
+    int mt = 16 * mi, pad = (Cout + mt - 1) / mt * mt;
+    if (pad < best_pad) {
+      best_pad = pad;
+      best = mi;
+    }
+  }
+  return best;
+}
+inline int nst_of(int k) { return k == 5 ? nq_conv3_nst_k5() : nq_conv3_nst_k3(); }
+
+// One thread per 16-byte fragment slot (c, s, tile, kq, co): 8 consecutive channels of one tap, split into bf16 hi/lo.
+// transposed = 0: logical conv == the stored conv, src(co, ch, tap) = w[co][ch][tap]
+// transposed = 1: data gradient, logical (Cin=Cout_w -> Cout=Cin_w): src(co, ch, tap) = w[ch][co][KK-1-tap]
+__global__ __launch_bounds__(256) void weight_layout3_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cin,
+                                                             int Cout, int KK, int NST, int nchunk, int co_tiles, int MT,
+                                                             int transposed) {
+  const int64_t slots = (int64_t)nchunk * NST * co_tiles * 4 * MT;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= slots) return;
+  const int co_l = (int)(i % MT);
+  const int kq = (int)((i / MT) % 4);
+  const int tile = (int)((i / (4 * MT)) % co_tiles);
+  const int s = (int)((i / ((int64_t)4 * MT * co_tiles)) % NST);
+  const int c = (int)(i / ((int64_t)4 * MT * co_tiles * NST));
+  const int co = tile * MT + co_l, tap = 2 * s + (kq >> 1), ch0 = c * CC + (kq & 1) * 8;
+  unsigned hi[4], lo[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float v[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int ch = ch0 + 2 * j + t;
+      float x = 0.f;
+      if (tap < KK && ch < Cin && co < Cout)
+        x = transposed ? w[((int64_t)ch * Cout + co) * KK + (KK - 1 - tap)] : w[((int64_t)co * Cin + ch) * KK + tap];
+      v[t] = x;
+    }
+    __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1];
+    __bf16 l0 = (__bf16)(v[0] - (float)h0), l1 = (__bf16)(v[1] - (float)h1);
+    hi[j] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    lo[j] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+  }
+  // [c][s][plane][tile][kq][MT]
+  const int64_t step = (int64_t)c * NST + s;
+  const int64_t plane_stride = (int64_t)co_tiles * 4 * MT;
+  const int64_t base = step * 2 * plane_stride + (int64_t)tile * 4 * MT + kq * MT + co_l;
+  out[base] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  out[base + plane_stride] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+struct Wg3Plan {
+  int mi, co_pad, n_pad, nsplit;
+};
+inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
+  Wg3Plan p;
+  p.mi = pick_mi3(Cout);
+  const int mt = 16 * p.mi, nt = 384, N = Cin * k * k;
+  p.co_pad = (Cout + mt - 1) / mt * mt;
+  p.n_pad = (N + nt - 1) / nt * nt;
+  const int tiles = (p.co_pad / mt) * (p.n_pad / nt);
+  const int nseg = ((W + 31) / 32) * H * B;
+  int ns = 512 / tiles;  // one full wave of workgroups (2 resident per CU)
+  if (ns > nseg) ns = nseg;
+  if (ns < 1) ns = 1;
+  p.nsplit = ns;
+  return p;
+}
+
+__global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ slab_db,
+                                                            float* __restrict__ dw, float* __restrict__ db, int Cout, int N,
+                                                            int co_pad, int n_pad, int nsplit) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)Cout * N;
+  if (i < total) {
+    int co = (int)(i / N), n = (int)(i - (int64_t)co * N);
+    const float* p = slab + (int64_t)co * n_pad + n;
+    const int64_t stride = (int64_t)co_pad * n_pad;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += p[k * stride];
+    dw[i] = s;
+  } else if (db && i < total + Cout) {
+    int co = (int)(i - total);
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += slab_db[(int64_t)k * co_pad + co];
+    db[co] = s;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nq_conv3_supported(int B, int Cin, int H, int W, int Cout, int k) {
+  if (!(k == 3 || k == 5) || B <= 0 || Cin <= 0 || Cout <= 4 || Cin <= 4) return 0;
+  const int mi = pick_mi3(Cout);
+  const int64_t wgs = (int64_t)((W + 31) / 32) * ((H + 7) / 8) * ((Cout + 16 * mi - 1) / (16 * mi)) * B;
+  return wgs >= 256;  // smaller grids stay on the fp32 split-K kernel
+}
+
+int64_t nq_conv3_weight_bytes(int Cin, int Cout, int k) {
+  if (!(k == 3 || k == 5)) return 0;
+  const int mi = pick_mi3(Cout), mt = 16 * mi;
+  const int64_t co_tiles = (Cout + mt - 1) / mt, nchunk = (Cin + CC - 1) / CC;
+  return nchunk * nst_of(k) * 2 * co_tiles * 4 * mt * 16;
+}
+
+// w: OIHW weight tensor of the STORED conv (Cout_w, Cin_w, k, k).  transposed = 0 -> operand of the forward conv
+// (Cin = Cin_w, Cout = Cout_w); transposed = 1 -> operand of its data gradient (Cin = Cout_w, Cout = Cin_w).
+int nq_weight_layout3(const float* w, void* wt3, int Cin, int Cout, int k, int transposed, nq_stream_t stream) {
+  if (!w || !wt3 || !(k == 3 || k == 5) || Cin <= 0 || Cout <= 0) return NQ_ERR_INVALID;
+  const int mi = pick_mi3(Cout), mt = 16 * mi, nst = nst_of(k);
+  const int co_tiles = (Cout + mt - 1) / mt, nchunk = (Cin + CC - 1) / CC;
+  const int64_t slots = (int64_t)nchunk * nst * co_tiles * 4 * mt;
+  hipLaunchKernelGGL(weight_layout3_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, nq_s(stream), w,
+                     reinterpret_cast<uint4*>(wt3), Cin, Cout, k * k, nst, nchunk, co_tiles, mt, transposed);
+  return nq_launch_status();
+}
+
+int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* y, float* z, const float* zprev, int B, int Cin,
+                     int H, int W, int Cout, int k, int r, int epilogue, nq_stream_t stream) {
+  if (!x || !wt3 || (!y && epilogue != NQ_EPI_PS) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
+  if (!(k == 3 || k == 5)) return NQ_ERR_UNSUPPORTED;
+  if (epilogue < 0 || epilogue > NQ_EPI_DGRAD_GELU) return NQ_ERR_INVALID;
+  if ((epilogue == NQ_EPI_PS_GELU || epilogue == NQ_EPI_PS) && (!z || r <= 0 || Cout % (r * r) != 0)) return NQ_ERR_INVALID;
+  if (epilogue == NQ_EPI_DGRAD_GELU && (!zprev || r <= 0 || H % r != 0 || W % r != 0)) return NQ_ERR_INVALID;
+  if (B > 65535) return NQ_ERR_UNSUPPORTED;
+  const int mi = pick_mi3(Cout);
+  hipStream_t st = nq_s(stream);
+  if (k == 3) return nq_conv_igemm3_k3(x, wt3, bias, y, z, zprev, B, Cin, H, W, Cout, r, epilogue, mi, st);
+  return nq_conv_igemm3_k5(x, wt3, bias, y, z, zprev, B, Cin, H, W, Cout, r, epilogue, mi, st);
+}
+
+int nq_conv_wgrad3_supported(int B, int Cin, int H, int W, int Cout, int k) {
+  if (!(k == 3 || k == 5) || B <= 0 || Cin <= 0 || Cout <= 4) return 0;
+  return (int64_t)((W + 31) / 32) * H * B >= 512;  // enough 32-pixel segments to fill the chip
+}
+
+int64_t nq_conv_wgrad3_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
+  if (!(k == 3 || k == 5) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  Wg3Plan p = plan_wgrad3(B, Cin, H, W, Cout, k);
+  return (int64_t)p.nsplit * p.co_pad * ((int64_t)p.n_pad + 1);
+}
+
+int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+                   int k, nq_stream_t stream) {
+  if (!x || !dy || !dw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
+  if (!(k == 3 || k == 5)) return NQ_ERR_UNSUPPORTED;
+  if ((int64_t)Cout * H * W >= (1ll << 31) || (int64_t)Cin * H * W >= (1ll << 31)) return NQ_ERR_UNSUPPORTED;
+  Wg3Plan p = plan_wgrad3(B, Cin, H, W, Cout, k);
+  float* slab = ws;
+  float* slab_db = ws + (int64_t)p.nsplit * p.co_pad * p.n_pad;
+  hipStream_t st = nq_s(stream);
+  int rc = (k == 3) ? nq_conv_wgrad3_k3(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, st)
+                    : nq_conv_wgrad3_k5(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, st);
+  if (rc != NQ_OK) return rc;
+  const int N = Cin * k * k;
+  int64_t total = (int64_t)Cout * N + Cout;
+  hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slab, slab_db, dw, db, Cout,
+                     N, p.co_pad, p.n_pad, p.nsplit);
+  return nq_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,351 @@
+// Implicit-GEMM convolution with fp32-equivalent accuracy on the BF16 matrix pipe ("bf16x3"):
+//   every fp32 operand x is split into x_hi = bf16(x), x_lo = bf16(x - x_hi) and each product is formed as
+//   a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with fp32 accumulation in v_mfma_f32_16x16x32_bf16 (the dropped lo*lo term is
+//   2^-16 relative, the same order as the fp32 rounding of a length-1000 dot product).  3 MFMAs of 16 cycles replace
+//   8 fp32 MFMAs of 32 cycles per 16x16x32 block: 5.3x the fp32-MFMA rate; stride 1, pad KS/2, NCHW fp32 in HBM.
+//   Included once per kernel size (NQ_KS = 3, 5).
+//
+// GEMM view as in conv_igemm_impl.h: D[co][pixel] = sum_k W[co][k] * X[k][pixel]; A = weights, B = activations, so the
+// accumulator/epilogue layout is identical to the fp32 kernel (16 pixels of a row on 16 lanes, 4 conv channels in a
+// lane's 4 registers).
+//
+// K order: input channels are processed in chunks of 16 (2 octets); one MFMA k-step (32) = 2 taps x 2 octets: lane
+// group kq = lane>>4 holds the 8 channels of octet (kq&1) at tap 2*step + (kq>>1).  (KS*KS is odd: the last step's
+// second tap has zero weights.)
+//
+// Workgroup = 4 waves = 8 rows x 32 columns of one frame x MT = 16*MI output channels (MI <= 5); wave w owns rows
+// 2w, 2w+1 = 4 pixel blocks: 4*MI accumulators.
+// LDS (bf16, hi and lo planes):
+//   patch  [2 buf][plane][octet][PH*PW pixels][8 ch]   16-byte fragment reads, 16 consecutive pixels -> conflict-free
+//   weights[2 buf][plane][kq][MT][8 k]                  streamed per k-step from a pre-split, pre-ordered global copy
+// The patch of the next channel chunk and the weights of the next step are loaded into registers before the MFMAs of
+// the current step and written to the other buffer after them; one barrier per step.
+//
+// Roofline: MFMA bf16 (2.5 PFLOP/s dense, 3 MFMA flops per algorithmic flop -> 833 TFLOP/s fp32-equivalent);
+// algorithmic flops = 2*Cout*Cin*KS^2*H*W*B.
+#include <type_traits>
+
+#include "nq_common.h"
+
+#ifndef NQ_KS
+#error "define NQ_KS before including conv_igemm3_impl.h"
+#endif
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+struct Conv3Args {
+  const float* x;
+  const void* wt3;  // [chunk][step][plane][co tile][kq][MT][8] bf16 (nq_weight_layout3)
+  const float* bias;
+  float* y;
+  float* z;
+  const float* zprev;
+  int B, Cin, H, W, Cout, r, epi, tiles_x, nchunk, co_tiles;
+};
+
+constexpr int KS = NQ_KS;
+constexpr int KK = KS * KS;
+constexpr int PAD = KS / 2;
+constexpr int TH = 8, TW = 32;
+constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
+constexpr int NPIX = PH * PW;
+constexpr int PP = (NPIX + 15) / 16 * 16;  // octet-plane stride in pixels (16-byte units): multiple of 256 B
+constexpr int NST = (KK + 1) / 2;          // k-steps per channel chunk
+constexpr int CC = 16;                     // channels per chunk
+constexpr int PATCH_U4 = 2 * 2 * PP;       // 16-byte units per patch buffer: [plane][octet][PP]
+constexpr int NITEM = 2 * NPIX;            // staging items (octet, pixel)
+constexpr int IPT = (NITEM + 255) / 256;
+
+template <int I0, int N, class F>
+__device__ __forceinline__ void steps3(F&& f) {
+  if constexpr (I0 < N) {
+    f(std::integral_constant<int, I0>{});
+    steps3<I0 + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ float gelu3(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu3_grad(float v) {
+  float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+  return cdf + v * pdf;
+}
+
+// split 8 floats into packed bf16 hi / lo vectors (round-to-nearest-even both times)
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    __bf16 h0 = (__bf16)v[2 * j], h1 = (__bf16)v[2 * j + 1];
+    __bf16 l0 = (__bf16)(v[2 * j] - (float)h0), l1 = (__bf16)(v[2 * j + 1] - (float)h1);
+    hi[j] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+    lo[j] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+  }
+}
+
+template <int MI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_igemm3_kernel(Conv3Args a) {
+  constexpr int MT = 16 * MI;
+  constexpr int W_U4 = 2 * 4 * MT;            // 16-byte units per weight buffer: [plane][kq][MT]
+  constexpr int WPT = (W_U4 + 255) / 256;     // per thread
+
+  extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
+  u32x4* const patch0 = smem;                  // 2 buffers of PATCH_U4
+  u32x4* const wl0 = smem + 2 * PATCH_U4;      // 2 buffers of W_U4
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+  const int x0 = tile_x * TW, y0 = tile_y * TH;
+  const int cot = blockIdx.y, co0 = cot * MT;
+  const int b = blockIdx.z;
+  const int H = a.H, W = a.W, Cin = a.Cin;
+  const int64_t HW = (int64_t)H * W;
+  const float* __restrict__ xb = a.x + (int64_t)b * Cin * HW;
+  // weights of (chunk c, step s): base + ((c*NST + s) * co_tiles*2 ... see nq_weight_layout3: [c][s][plane][tile][kq][MT]
+  const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(a.wt3);
+  const int64_t w_plane_stride = (int64_t)a.co_tiles * 4 * MT;   // in 16-byte units
+  const int64_t w_step_stride = 2 * w_plane_stride;
+
+  // ---- staging state ----
+  float pv[IPT][8];
+  u32x4 wv[WPT];
+#define NQ3_LOAD_PATCH(CH)                                                                            \
+  {                                                                                                   \
+    int t_ = tid;                                                                                     \
+    asm volatile("" : "+v"(t_));                                                                      \
+    _Pragma("unroll") for (int i = 0; i < IPT; ++i) {                                                 \
+      const int e_ = t_ + i * 256;                                                                    \
+      const int oct_ = e_ / NPIX, pix_ = e_ - oct_ * NPIX;                                            \
+      const int py_ = pix_ / PW, px_ = pix_ - py_ * PW;                                               \
+      const int gy_ = y0 - PAD + py_, gx_ = x0 - PAD + px_;                                           \
+      const bool ok_ = (e_ < NITEM) && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;                    \
+      const int ch0_ = (CH) * CC + oct_ * 8;                                                          \
+      const float* p_ = xb + (int64_t)ch0_ * HW + (int64_t)gy_ * W + gx_;                             \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                   \
+          pv[i][j] = (ok_ && ch0_ + j < Cin) ? p_[(int64_t)j * HW] : 0.f;                             \
+    }                                                                                                 \
+  }
+#define NQ3_STORE_PATCH(DST)                                                                          \
+  {                                                                                                   \
+    int t_ = tid;                                                                                     \
+    asm volatile("" : "+v"(t_));                                                                      \
+    _Pragma("unroll") for (int i = 0; i < IPT; ++i) {                                                 \
+      const int e_ = t_ + i * 256;                                                                    \
+      if (e_ < NITEM) {                                                                               \
+        const int oct_ = e_ / NPIX, pix_ = e_ - oct_ * NPIX;                                          \
+        u32x4 hi_, lo_;                                                                               \
+        split8(pv[i], hi_, lo_);                                                                      \
+        (DST)[oct_ * PP + pix_] = hi_;                                                                \
+        (DST)[2 * PP + oct_ * PP + pix_] = lo_;                                                       \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+#define NQ3_LOAD_W(CH, ST)                                                                            \
+  {                                                                                                   \
+    const u32x4* __restrict__ src_ = wg + ((int64_t)(CH) * NST + (ST)) * w_step_stride + (int64_t)cot * 4 * MT; \
+    _Pragma("unroll") for (int i = 0; i < WPT; ++i) {                                                 \
+      const int f_ = tid + i * 256;                                                                   \
+      if (i + 1 < WPT || f_ < W_U4) {                                                                 \
+        const int pl_ = f_ / (4 * MT), rem_ = f_ - pl_ * (4 * MT);                                    \
+        wv[i] = src_[pl_ * w_plane_stride + rem_];                                                    \
+      }                                                                                               \
+    }                                                                                                 \
+  }
+#define NQ3_STORE_W(DST)                                                                              \
+  _Pragma("unroll") for (int i = 0; i < WPT; ++i) {                                                   \
+    const int f_ = tid + i * 256;                                                                     \
+    if (i + 1 < WPT || f_ < W_U4) (DST)[f_] = wv[i];                                                  \
+  }
+
+  f32x4 acc[MI][4];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) acc[mi][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // B fragment base (16-byte units): octet (kq&1), pixel (row 2*wave, col l16); + tap offset + block offset
+  const int b_lane = (kq & 1) * PP + (2 * wave) * PW + l16;
+  const bool odd_tap = (kq >> 1) != 0;
+  // A fragment base (16-byte units): [kq][MT] + l16
+  const int a_lane = kq * MT + l16;
+
+  // ---- prologue ----
+  const int nchunk = a.nchunk;
+  NQ3_LOAD_PATCH(0)
+  NQ3_LOAD_W(0, 0)
+  NQ3_STORE_PATCH(patch0)
+  NQ3_STORE_W(wl0)
+  __syncthreads();
+
+  int wbuf = 0;
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const u32x4* __restrict__ pb = patch0 + (ch & 1) * PATCH_U4 + b_lane;
+    steps3<0, NST>([&](auto st_c) {
+      constexpr int st = decltype(st_c)::value;
+      constexpr bool last_step = (st == NST - 1);
+      const bool more_w = !(last_step && ch + 1 == nchunk);
+      const bool new_patch = last_step && (ch + 1 < nchunk);
+      if (more_w) {
+        if constexpr (last_step) {
+          NQ3_LOAD_W(ch + 1, 0)
+        } else {
+          NQ3_LOAD_W(ch, st + 1)
+        }
+      }
+      if (new_patch) {
+        NQ3_LOAD_PATCH(ch + 1)
+      }
+      // taps of this step: even lane groups -> tap 2*st, odd -> tap 2*st+1 (clamped; its weights are zero when padded)
+      constexpr int te = 2 * st, to_ = (2 * st + 1 < KK) ? 2 * st + 1 : KK - 1;
+      constexpr int off_e = (te / KS) * PW + (te % KS), off_o = (to_ / KS) * PW + (to_ % KS);
+      const u32x4* __restrict__ pbt = pb + (odd_tap ? off_o : off_e);
+      const u32x4* __restrict__ wb = wl0 + wbuf * W_U4 + a_lane;
+      // B fragments of the wave's 4 pixel blocks (rows 2w, 2w+1 x 2 column halves), hi and lo planes
+      bf16x8 bh[4], bl[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int o = (nb >> 1) * PW + (nb & 1) * 16;
+        bh[nb] = __builtin_bit_cast(bf16x8, pbt[o]);
+        bl[nb] = __builtin_bit_cast(bf16x8, pbt[2 * PP + o]);
+      }
+      bf16x8 ah0 = __builtin_bit_cast(bf16x8, wb[0]), al0 = __builtin_bit_cast(bf16x8, wb[4 * MT]);
+      steps3<0, MI>([&](auto mi_c) {
+        constexpr int mi = decltype(mi_c)::value;
+        bf16x8 ah = ah0, al = al0;
+        if constexpr (mi + 1 < MI) {  // prefetch the next channel block's fragments
+          ah0 = __builtin_bit_cast(bf16x8, wb[(mi + 1) * 16]);
+          al0 = __builtin_bit_cast(bf16x8, wb[4 * MT + (mi + 1) * 16]);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nb], acc[mi][nb], 0, 0, 0);
+          acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nb], acc[mi][nb], 0, 0, 0);
+          acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nb], acc[mi][nb], 0, 0, 0);
+        }
+      });
+      if (more_w) {
+        u32x4* wdst = wl0 + (wbuf ^ 1) * W_U4;
+        NQ3_STORE_W(wdst)
+      }
+      if (new_patch) {
+        u32x4* pdst = patch0 + ((ch + 1) & 1) * PATCH_U4;
+        NQ3_STORE_PATCH(pdst)
+      }
+      __syncthreads();
+      wbuf ^= 1;
+    });
+  }
+#undef NQ3_LOAD_PATCH
+#undef NQ3_STORE_PATCH
+#undef NQ3_LOAD_W
+#undef NQ3_STORE_W
+
+  // ---- epilogue (same element mapping as conv_igemm_impl.h; nb = (row 2w + nb/2, column half nb%2)) ----
+  const int Cout = a.Cout, epi = a.epi, r = a.r, rr = a.r * a.r;
+  const int cob = co0 + 4 * kq;
+  steps3<0, MI>([&](auto mi_c) {
+    constexpr int mi = decltype(mi_c)::value;
+    const int co = cob + mi * 16;  // first of the lane's 4 channels (multiple of 4)
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int py = y0 + 2 * wave + (nb >> 1), px = x0 + (nb & 1) * 16 + l16;
+      if (py >= H || px >= W) continue;
+      const f32x4 v4 = acc[mi][nb];
+      if ((epi == NQ_EPI_PS || epi == NQ_EPI_PS_GELU) && (r == 2 || r == 4)) {
+        if (co >= Cout) continue;  // Cout % 4 == 0 here
+        const float4 bv = a.bias ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float v0 = v4[0] + bv.x, v1 = v4[1] + bv.y, v2 = v4[2] + bv.z, v3 = v4[3] + bv.w;
+        const int C = Cout / rr, c = co / rr;
+        const int si = (r == 4) ? ((co >> 2) & 3) : 0;
+        const int64_t rowbase = (((int64_t)b * C + c) * (H * r) + (int64_t)py * r + si) * ((int64_t)W * r);
+        if (r == 2) {
+          const int64_t o0 = rowbase + (int64_t)px * 2, o1 = o0 + (int64_t)W * 2;
+          *reinterpret_cast<float2*>(a.z + o0) = make_float2(v0, v1);
+          *reinterpret_cast<float2*>(a.z + o1) = make_float2(v2, v3);
+          if (epi == NQ_EPI_PS_GELU) {
+            *reinterpret_cast<float2*>(a.y + o0) = make_float2(gelu3(v0), gelu3(v1));
+            *reinterpret_cast<float2*>(a.y + o1) = make_float2(gelu3(v2), gelu3(v3));
+          }
+        } else {
+          const int64_t o0 = rowbase + (int64_t)px * 4;
+          *reinterpret_cast<float4*>(a.z + o0) = make_float4(v0, v1, v2, v3);
+          if (epi == NQ_EPI_PS_GELU)
+            *reinterpret_cast<float4*>(a.y + o0) = make_float4(gelu3(v0), gelu3(v1), gelu3(v2), gelu3(v3));
+        }
+        continue;
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int cc = co + reg;
+        if (cc >= Cout) continue;
+        float v = v4[reg] + (a.bias ? a.bias[cc] : 0.f);
+        if (epi == NQ_EPI_PS_GELU || epi == NQ_EPI_PS) {
+          const int C = Cout / rr, c = cc / rr, rem = cc - c * rr, si = rem / r, sj = rem - si * r;
+          const int64_t o = (((int64_t)b * C + c) * (H * r) + (int64_t)py * r + si) * ((int64_t)W * r) + (int64_t)px * r + sj;
+          a.z[o] = v;
+          if (epi == NQ_EPI_PS_GELU) a.y[o] = gelu3(v);
+        } else if (epi == NQ_EPI_DGRAD_GELU) {
+          const int64_t i = ((int64_t)b * Cout + cc) * HW + (int64_t)py * W + px;
+          v *= gelu3_grad(a.zprev[i]);
+          if (r == 1) {
+            a.y[i] = v;
+          } else {
+            const int yq = py / r, xq = px / r;
+            const int chn = cc * rr + (py - yq * r) * r + (px - xq * r);
+            a.y[(((int64_t)b * Cout * rr + chn) * (H / r) + yq) * (int64_t)(W / r) + xq] = v;
+          }
+        } else {
+          const int64_t o = ((int64_t)b * Cout + cc) * HW + (int64_t)py * W + px;
+          a.y[o] = (epi == NQ_EPI_TANH) ? tanhf(v) * 0.5f + 0.5f : v;
+        }
+      }
+    }
+  });
+}
+
+template <int MI>
+int launch_igemm3(const Conv3Args& a, int tiles, hipStream_t st) {
+  constexpr int MT = 16 * MI;
+  size_t lds = (size_t)(2 * PATCH_U4 + 2 * 2 * 4 * MT) * 16;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm3_kernel<MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return NQ_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv_igemm3_kernel<MI>, dim3((unsigned)tiles, (unsigned)a.co_tiles, (unsigned)a.B), dim3(256), lds, st, a);
+  return nq_launch_status();
+}
+
+}  // namespace
+
+#define NQ_CAT2(a, b) a##b
+#define NQ_CAT(a, b) NQ_CAT2(a, b)
+
+extern "C" int NQ_CAT(nq_conv_igemm3_k, NQ_KS)(const float* x, const void* wt3, const float* bias, float* y, float* z,
+                                                const float* zprev, int B, int Cin, int H, int W, int Cout, int r, int epi,
+                                                int mi_sel, hipStream_t st) {
+  Conv3Args a;
+  a.x = x; a.wt3 = wt3; a.bias = bias; a.y = y; a.z = z; a.zprev = zprev;
+  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.r = r; a.epi = epi;
+  a.tiles_x = (W + TW - 1) / TW;
+  a.nchunk = (Cin + CC - 1) / CC;
+  a.co_tiles = (Cout + 16 * mi_sel - 1) / (16 * mi_sel);
+  const int tiles = a.tiles_x * ((H + TH - 1) / TH);
+  switch (mi_sel) {
+    case 1: return launch_igemm3<1>(a, tiles, st);
+    case 2: return launch_igemm3<2>(a, tiles, st);
+    case 3: return launch_igemm3<3>(a, tiles, st);
+    case 4: return launch_igemm3<4>(a, tiles, st);
+    case 5: return launch_igemm3<5>(a, tiles, st);
+    default: return NQ_ERR_UNSUPPORTED;
+  }
+}
+
+// steps per chunk for this kernel size (used by nq_weight_layout3)
+extern "C" int NQ_CAT(nq_conv3_nst_k, NQ_KS)() { return NST; }

@@ -1,0 +1,329 @@
+// Weight/bias gradient of the stride-1 convolution with fp32-equivalent accuracy on the BF16 matrix pipe ("bf16x3",
+// see conv_igemm3_impl.h for the operand split).  Included once per kernel size (NQ_KS = 3, 5).
+//
+// GEMM view as conv_wgrad_impl.h:  dW[co][n] = sum_pixels dY[co][p] * X[n][p],  n = (ci,kh,kw), K = pixels, split over
+// workgroups into slabs that are reduced in fixed order (deterministic).  One MFMA k-step = 32 consecutive pixels of
+// an image row: lane group kq = lane>>4 holds pixels 8*kq .. 8*kq+7.
+//
+// Workgroup = 4 waves; tile = MT = 16*MI channels x NT = 64*NI n-values; wave w owns n-columns [16*NI*w, 16*NI*(w+1)).
+// LDS per 32-pixel segment (double-buffered, one barrier per segment):
+//   dY  [plane hi/lo][kq][MT][8 px] bf16  -> A fragments are conflict-free 16-byte reads
+//   x   [CIT][KS][32+KS-1] 32-bit words {hi16,lo16}, row stride == KS, plane stride == KS*KS (mod 32) so that
+//       bank(n) = n mod 32: a B fragment = 8 conflict-free 4-byte reads at the lane's (ci,kh,kw) offset + 8 v_perm
+// Operands are split (two v_cvt_pk_bf16_f32 + one subtract per element) once, while staging.
+//
+// Roofline: MFMA bf16, 3 MFMA flops per algorithmic flop (833 TFLOP/s fp32-equivalent); algorithmic flops as fp32.
+#include <type_traits>
+
+#include "nq_common.h"
+
+#ifndef NQ_KS
+#error "define NQ_KS before including conv_wgrad3_impl.h"
+#endif
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef f32x4 f32x4_u __attribute__((aligned(4)));
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+struct Wgrad3Args {
+  const float* x;
+  const float* dy;
+  float* slab;     // [nsplit][co_pad][n_pad]
+  float* slab_db;  // [nsplit][co_pad]
+  int B, Cin, H, W, Cout, N, co_pad, n_pad, segs_x, nseg, nsplit;
+};
+
+constexpr int KS = NQ_KS;
+constexpr int KK = KS * KS;
+constexpr int PAD = KS / 2;
+constexpr int SEG = 32;
+constexpr int RW = SEG + KS - 1;
+constexpr int PWS = [] {  // x row stride (words): >= RW and == KS (mod 32)
+  int v = RW;
+  while (v % 32 != KS % 32) ++v;
+  return v;
+}();
+constexpr int PSX = KS * PWS;  // plane stride (== KS*KS mod 32)
+
+template <int I0, int N, class F>
+__device__ __forceinline__ void wg3_steps(F&& f) {
+  if constexpr (I0 < N) {
+    f(std::integral_constant<int, I0>{});
+    wg3_steps<I0 + 1, N>(f);
+  }
+}
+
+__device__ __forceinline__ unsigned split_word(float v) {  // {hi16, lo16}
+  __bf16 h = (__bf16)v;
+  __bf16 l = (__bf16)(v - (float)h);
+  return ((unsigned)__builtin_bit_cast(unsigned short, h) << 16) | (unsigned)__builtin_bit_cast(unsigned short, l);
+}
+
+template <int MI, int NI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_wgrad3_kernel(Wgrad3Args a) {
+  constexpr int MT = 16 * MI, NT = 64 * NI;
+  constexpr int CIT = (NT + KK - 2) / KK + 1;
+  constexpr int DZ_U4 = 2 * 4 * MT;              // 16-byte units: [plane][kq][MT]
+  constexpr int X_WORDS = CIT * PSX;
+  constexpr int BUF_BYTES = DZ_U4 * 16 + ((X_WORDS * 4 + 15) / 16) * 16;
+  constexpr int DITEMS = 4 * MT;                 // (co, kq) staging items of 8 pixels
+  constexpr int DPT = (DITEMS + 255) / 256;
+  constexpr int Q = (RW + 3) / 4;
+  constexpr int XF = CIT * KS * Q;               // 16-byte x staging slots
+  constexpr int XPT4 = (XF + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int split = blockIdx.x;
+  const int n0 = blockIdx.y * NT;
+  const int co0 = blockIdx.z * MT;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, N = a.N;
+  const int ci0 = n0 / KK;
+  const int64_t HW = (int64_t)H * W;
+
+  // per-lane B-fragment constants (word offsets)
+  int lc[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    int n = n0 + (wave * NI + ni) * 16 + l16;
+    if (n > N - 1) n = N - 1;
+    const int ci = n / KK, rem = n - ci * KK;
+    const int kh = rem / KS, kw = rem - kh * KS;
+    lc[ni] = (ci - ci0) * PSX + kh * PWS + kw + 8 * kq;
+  }
+  const int a_lane = kq * MT + l16;
+
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float db_part[DPT];
+#pragma unroll
+  for (int i = 0; i < DPT; ++i) db_part[i] = 0.f;
+  const bool do_db = (blockIdx.y == 0) && a.slab_db != nullptr;
+
+  const int seg_lo = (int)(((int64_t)a.nseg * split) / a.nsplit);
+  const int seg_hi = (int)(((int64_t)a.nseg * (split + 1)) / a.nsplit);
+
+  // ---- staging plan ----
+  // dY item e = tid + 256*i -> (co = e >> 2, kq = e & 3): pixels 8*kq..8*kq+7 of row co (two 16-byte loads)
+  // x slot  e -> (row = e / Q, q = e % Q), row = (ci_l, r)
+  int xoff[XPT4], xlds[XPT4], xrc[XPT4];
+#pragma unroll
+  for (int i = 0; i < XPT4; ++i) {
+    const int e = tid + i * 256;
+    const int row = e / Q, q = e - row * Q;
+    const int ci_l = row / KS, r = row - ci_l * KS;
+    const bool ok = (e < XF) && (ci0 + ci_l < Cin);
+    xoff[i] = (ci0 + ci_l) * (int)HW + (r - PAD) * W + 4 * q - PAD;
+    xlds[i] = ok ? ci_l * PSX + r * PWS + 4 * q : -1;
+    xrc[i] = r * 4096 + 4 * q;
+  }
+  f32x4 dv[DPT][2], xv[XPT4];
+  auto load_seg = [&](int seg) {
+    const int xs = seg % a.segs_x;
+    const int by = seg / a.segs_x;
+    const int y = by % H, b = by / H;
+    const int x0 = xs * SEG;
+    const float* __restrict__ dyp = a.dy + (int64_t)b * Cout * HW + (int64_t)y * W + x0;
+    const float* __restrict__ xp = a.x + (int64_t)b * Cin * HW + (int64_t)y * W + x0;
+    const bool seg_full = (x0 + SEG <= W);
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      const int e = tid + i * 256;
+      const int co = e >> 2, q8 = (e & 3) * 8;
+      f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
+      if (e < DITEMS && co0 + co < Cout) {
+        const float* p = dyp + (int64_t)(co0 + co) * HW + q8;
+        if (seg_full) {
+          v0 = *reinterpret_cast<const f32x4_u*>(p);
+          v1 = *reinterpret_cast<const f32x4_u*>(p + 4);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (x0 + q8 + j < W) v0[j] = p[j];
+            if (x0 + q8 + 4 + j < W) v1[j] = p[4 + j];
+          }
+        }
+      }
+      dv[i][0] = v0;
+      dv[i][1] = v1;
+    }
+#pragma unroll
+    for (int i = 0; i < XPT4; ++i) {
+      f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (xlds[i] >= 0) {
+        const int gy = y + (xrc[i] >> 12) - PAD, gx0 = x0 + (xrc[i] & 4095) - PAD;
+        if (gy >= 0 && gy < H) {
+          const float* p = xp + xoff[i];
+          if (gx0 >= 0 && gx0 + 3 < W) {
+            v = *reinterpret_cast<const f32x4_u*>(p);
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (gx0 + j >= 0 && gx0 + j < W) v[j] = p[j];
+          }
+        }
+      }
+      xv[i] = v;
+    }
+  };
+  auto store_seg = [&](unsigned char* buf) {
+    u32x4* dz = reinterpret_cast<u32x4*>(buf);
+    unsigned* xw = reinterpret_cast<unsigned*>(buf + DZ_U4 * 16);
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      const int e = tid + i * 256;
+      if (e < DITEMS) {
+        const int co = e >> 2, q = e & 3;
+        u32x4 hi, lo;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float f0 = (j < 2) ? dv[i][0][2 * j] : dv[i][1][2 * j - 4];
+          const float f1 = (j < 2) ? dv[i][0][2 * j + 1] : dv[i][1][2 * j - 3];
+          s += f0 + f1;
+          const unsigned w0 = split_word(f0), w1 = split_word(f1);
+          hi[j] = (w0 >> 16) | (w1 & 0xffff0000u);
+          lo[j] = (w0 & 0xffffu) | (w1 << 16);
+        }
+        db_part[i] += s;
+        dz[q * MT + co] = hi;
+        dz[4 * MT + q * MT + co] = lo;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XPT4; ++i) {
+      if (xlds[i] >= 0) {
+        const int cc = xrc[i] & 4095;
+        unsigned* d = xw + xlds[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (cc + j < RW) d[j] = split_word(xv[i][j]);
+      }
+    }
+  };
+
+  if (seg_lo < seg_hi) {
+    load_seg(seg_lo);
+    store_seg(smem);
+    __syncthreads();
+    if (seg_lo + 1 < seg_hi) load_seg(seg_lo + 1);
+  }
+  for (int seg = seg_lo; seg < seg_hi; ++seg) {
+    const int cur = (seg - seg_lo) & 1;
+    const u32x4* __restrict__ dz = reinterpret_cast<const u32x4*>(smem + cur * BUF_BYTES) + a_lane;
+    const unsigned* __restrict__ xw = reinterpret_cast<const unsigned*>(smem + cur * BUF_BYTES + DZ_U4 * 16);
+    // B fragments: 8 words per n-block -> hi / lo vectors
+    bf16x8 bh[NI], bl[NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      unsigned w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = xw[lc[ni] + j];
+      u32x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hi[j] = (w[2 * j] >> 16) | (w[2 * j + 1] & 0xffff0000u);
+        lo[j] = (w[2 * j] & 0xffffu) | (w[2 * j + 1] << 16);
+      }
+      bh[ni] = __builtin_bit_cast(bf16x8, hi);
+      bl[ni] = __builtin_bit_cast(bf16x8, lo);
+    }
+    bf16x8 ah0 = __builtin_bit_cast(bf16x8, dz[0]), al0 = __builtin_bit_cast(bf16x8, dz[4 * MT]);
+    wg3_steps<0, MI>([&](auto mi_c) {
+      constexpr int mi = decltype(mi_c)::value;
+      bf16x8 ah = ah0, al = al0;
+      if constexpr (mi + 1 < MI) {
+        ah0 = __builtin_bit_cast(bf16x8, dz[(mi + 1) * 16]);
+        al0 = __builtin_bit_cast(bf16x8, dz[4 * MT + (mi + 1) * 16]);
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
+        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ni], acc[mi][ni], 0, 0, 0);
+      }
+    });
+    if (seg + 1 < seg_hi) store_seg(smem + (cur ^ 1) * BUF_BYTES);
+    __syncthreads();
+    if (seg + 2 < seg_hi) load_seg(seg + 2);
+  }
+
+  // ---- write the partial slab ----
+  float* __restrict__ slab = a.slab + (int64_t)split * a.co_pad * a.n_pad;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + (wave * NI + ni) * 16 + l16;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = co0 + mi * 16 + 4 * kq + reg;
+        slab[(int64_t)co * a.n_pad + n] = acc[mi][ni][reg];
+      }
+    }
+  if (do_db) {  // bias gradient: per-thread fp32 sums of the staged dY values, combined in fixed order
+    float* red = reinterpret_cast<float*>(smem);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      const int e = tid + i * 256;
+      if (e < DITEMS) red[e] = db_part[i];   // red[co*4 + kq]
+    }
+    __syncthreads();
+    if (tid < MT) a.slab_db[(int64_t)split * a.co_pad + co0 + tid] = (red[4 * tid] + red[4 * tid + 1]) + (red[4 * tid + 2] + red[4 * tid + 3]);
+  }
+}
+
+constexpr int ni3_for(int mi) { return mi <= 3 ? 6 : (mi <= 4 ? 6 : 6); }
+
+template <int MI, int NI>
+int launch_wgrad3(const Wgrad3Args& a, hipStream_t st) {
+  constexpr int MT = 16 * MI, NT = 64 * NI;
+  constexpr int CIT = (NT + KK - 2) / KK + 1;
+  constexpr int BUF_BYTES = 2 * 4 * MT * 16 + ((CIT * PSX * 4 + 15) / 16) * 16;
+  size_t lds = (size_t)2 * BUF_BYTES;
+  dim3 grid((unsigned)a.nsplit, (unsigned)(a.n_pad / NT), (unsigned)(a.co_pad / MT));
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_kernel<MI, NI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return NQ_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_wgrad3_kernel<MI, NI>), grid, dim3(256), lds, st, a);
+  return nq_launch_status();
+}
+
+}  // namespace
+
+#define NQ_CAT2(a, b) a##b
+#define NQ_CAT(a, b) NQ_CAT2(a, b)
+
+// tile: MT = 16*mi_sel channels (mi_sel in 1..5), NT = 384 n-values
+extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, float* slab, float* slab_db, int B, int Cin,
+                                                int H, int W, int Cout, int co_pad, int n_pad, int nsplit, int mi_sel,
+                                                hipStream_t st) {
+  Wgrad3Args a;
+  a.x = x; a.dy = dy; a.slab = slab; a.slab_db = slab_db;
+  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.N = Cin * KK;
+  a.co_pad = co_pad; a.n_pad = n_pad;
+  a.segs_x = (W + SEG - 1) / SEG;
+  a.nseg = a.segs_x * H * B;
+  a.nsplit = nsplit;
+  switch (mi_sel) {
+    case 1: return launch_wgrad3<1, 6>(a, st);
+    case 2: return launch_wgrad3<2, 6>(a, st);
+    case 3: return launch_wgrad3<3, 6>(a, st);
+    case 4: return launch_wgrad3<4, 6>(a, st);
+    case 5: return launch_wgrad3<5, 6>(a, st);
+    default: return NQ_ERR_UNSUPPORTED;
+  }
+}

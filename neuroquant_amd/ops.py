@@ -6,6 +6,7 @@ its tensors are not fp32 HIP tensors or if libnqhip.so is missing.
 """
 import ctypes
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -317,6 +318,54 @@ def conv_forward_raw(x, wt, dims, bias, cout, k, epilogue, r, in_gelu=False, zpr
     return y, z
 
 
+def conv3_supported(B, cin, H, W, cout, k):
+    return bool(L.lib().nq_conv3_supported(B, cin, H, W, cout, k))
+
+
+def weight_layout3(w, transposed=False):
+    """pre-split (bf16 hi/lo) operand of the bf16x3 conv kernels; transposed=True -> operand of the data gradient."""
+    w = _dev(w)
+    cw_out, cw_in, k, _ = w.shape
+    cin, cout = (cw_out, cw_in) if transposed else (cw_in, cw_out)
+    buf = torch.empty(L.lib().nq_conv3_weight_bytes(cin, cout, k), device=w.device, dtype=torch.uint8)
+    L.check(L.lib().nq_weight_layout3(_p(w), _p(buf), cin, cout, k, 1 if transposed else 0, _stream()), "weight_layout3")
+    return buf
+
+
+def conv3_forward_raw(x, wt3, bias, cout, k, epilogue, r, zprev=None):
+    """bf16x3 counterpart of conv_forward_raw (same outputs)."""
+    B, cin, H, W = x.shape
+    y = z = None
+    if epilogue in (EPI_PS_GELU, EPI_PS):
+        z = torch.empty((B, cout // (r * r), H * r, W * r), device=x.device, dtype=torch.float32)
+        if epilogue == EPI_PS_GELU:
+            y = torch.empty_like(z)
+    elif epilogue == EPI_DGRAD_GELU:
+        y = torch.empty((B, cout * r * r, H // r, W // r), device=x.device, dtype=torch.float32)
+    else:
+        y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+    _timed(("conv_igemm3", k, cin, cout, H, W, B, epilogue),
+           lambda: L.check(L.lib().nq_conv_forward3(_p(x), _p(wt3), _p(bias), _p(y), _p(z), _p(zprev), B, cin, H, W, cout, k,
+                                                    r, epilogue, _stream()), "conv_forward3"))
+    return y, z
+
+
+def conv_wgrad3_supported(B, cin, H, W, cout, k):
+    return bool(L.lib().nq_conv_wgrad3_supported(B, cin, H, W, cout, k))
+
+
+def conv_wgrad3_raw(x, dy, cout, k, want_db):
+    """bf16x3 counterpart of conv_wgrad_raw."""
+    B, cin, H, W = x.shape
+    ws = torch.empty(L.lib().nq_conv_wgrad3_ws_floats(B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
+    dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32)
+    db = torch.empty(cout, device=x.device, dtype=torch.float32) if want_db else None
+    _timed(("conv_wgrad3", k, cin, cout, H, W, B, 0),
+           lambda: L.check(L.lib().nq_conv_wgrad3(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k, _stream()),
+                           "conv_wgrad3"))
+    return dw, db
+
+
 def conv_wgrad_raw(x, dy, cout, k, want_db, x_gelu=False):
     B, cin, H, W = x.shape
     ws = torch.empty(L.lib().nq_conv_wgrad_ws_floats(B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
@@ -377,10 +426,15 @@ class DecoderSpec:
     """Static description of a conv decoder stack for `decoder_stack`: per layer (k, shuffle r, gelu after),
     the (fc_h, fc_w) channel->space reshape after layer 0 and whether OutImg is tanh*0.5+0.5."""
 
-    def __init__(self, layers, fc_hw=(1, 1), tanh_out=True, materialize_act=True):
+    def __init__(self, layers, fc_hw=(1, 1), tanh_out=True, materialize_act=True, precision=None):
         self.layers = [tuple(l) for l in layers]
         self.fc_hw = tuple(fc_hw)
         self.tanh_out = tanh_out
+        # 'bf16x3': convolutions whose grid fills the chip run on the BF16 matrix pipe with split fp32 operands
+        # (hi*hi + hi*lo + lo*hi, fp32 accumulate; see conv_igemm3_impl.h); 'fp32': exact fp32 MFMA everywhere.
+        self.precision = precision or os.environ.get("NQ_CONV_PRECISION", "bf16x3")
+        if self.precision not in ("fp32", "bf16x3"):
+            raise ValueError(f"unknown conv precision {self.precision!r}")
         # True : each block's epilogue writes z AND a = gelu(z); consumers read a (one erf per element).
         # False: only z is written and every consumer applies GELU while staging its tile (less HBM traffic, but the
         #        halo / per-tap re-reads repeat the erf 2-6x; measured slower on MI355X, kept for comparison).
@@ -417,7 +471,17 @@ class _DecoderStackFn(Function):
             W = _dev(wb[2 * l], "weight")
             b = _dev(wb[2 * l + 1], "bias") if wb[2 * l + 1] is not None else None
             cout, cin = W.shape[0], W.shape[1]
-            wt, dims, wbk, dims_b = weight_layouts(W, need_bwd=(l > 0))
+            Bx, _, Hx, Wx = x.shape
+            use3 = spec.precision == "bf16x3" and not in_gelu and conv3_supported(Bx, cin, Hx, Wx, cout, k)
+            use3_bwd = spec.precision == "bf16x3" and l > 0 and conv3_supported(Bx, cout, Hx, Wx, cin, k)
+            if use3:
+                wt3 = weight_layout3(W)
+                wt, dims = None, None
+            else:
+                wt, dims, _, _ = weight_layouts(W, need_bwd=False)
+            wbk = dims_b = None
+            if l > 0 and not use3_bwd:
+                _, _, wbk, dims_b = weight_layouts(W, need_bwd=True)
             last = l == n - 1
             if last:
                 epi = EPI_TANH if spec.tanh_out else EPI_PLAIN
@@ -427,10 +491,13 @@ class _DecoderStackFn(Function):
                 epi = EPI_PS
             else:
                 epi = EPI_PLAIN
-            y, z = conv_forward_raw(x, wt, dims, b, cout, k, epi, r, in_gelu=in_gelu)
+            if use3:
+                y, z = conv3_forward_raw(x, wt3, b, cout, k, epi, r)
+            else:
+                y, z = conv_forward_raw(x, wt, dims, b, cout, k, epi, r, in_gelu=in_gelu)
             saved_in.append(x)
             saved_z.append(zprev)
-            metas.append((k, r, act, cout, cin, in_gelu, wbk, dims_b, b is not None))
+            metas.append((k, r, act, cout, cin, in_gelu, wbk, dims_b, b is not None, W if use3_bwd else None))
             if epi == EPI_PS_GELU:
                 x, zprev, in_gelu = y, z, False
             elif epi == EPI_PS:
@@ -456,19 +523,26 @@ class _DecoderStackFn(Function):
             dconv = g
         grads = [None] * (2 * n)
         for l in range(n - 1, -1, -1):
-            k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b = metas[l]
+            k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
             x_in = xs[l]
-            dw, db = conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu)
+            if spec.precision == "bf16x3" and not in_gelu and conv_wgrad3_supported(x_in.shape[0], cin, x_in.shape[2],
+                                                                                    x_in.shape[3], cout, k):
+                dw, db = conv_wgrad3_raw(x_in, dconv, cout, k, has_b)
+            else:
+                dw, db = conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu)
             grads[2 * l], grads[2 * l + 1] = dw, db
             if l == 0:
                 break
             kp, rp, actp = spec.layers[l - 1]
-            if actp:   # the layer below ends in GELU: d(pre-activation) = dgrad * gelu'(z), stored as ITS conv-output grad
-                dconv, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, EPI_DGRAD_GELU, rp, zprev=zs[l])
+            epi_b, r_b, zp = (EPI_DGRAD_GELU, rp, zs[l]) if actp else (EPI_PLAIN, 1, None)
+            if not actp and rp != 1:
+                raise NotImplementedError("PixelShuffle without activation between decoder layers")
+            # the layer below ends in GELU: d(pre-activation) = dgrad * gelu'(z), stored as ITS conv-output gradient
+            if W3 is not None:
+                dconv, _ = conv3_forward_raw(dconv, weight_layout3(W3, transposed=True), None, cin, k, epi_b, r_b, zprev=zp)
             else:
-                if rp != 1:
-                    raise NotImplementedError("PixelShuffle without activation between decoder layers")
-                dconv, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, EPI_PLAIN, 1)
+                dconv, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, epi_b, r_b, zprev=zp)
+            if not actp:
                 if l == 1 and spec.fc_hw != (1, 1):
                     dconv = _channels_from_space(dconv, *spec.fc_hw).contiguous()
         return (None, None) + tuple(grads)
