@@ -16,9 +16,13 @@ namespace {
 
 constexpr int CC = 16;
 
+// channel blocks (of 16) per workgroup: fewest padded channels among the wide tiles (narrow tiles re-read the
+// activation patch once per tile and run too few MFMAs per barrier), narrow tiles only for narrow layers
 inline int pick_mi3(int Cout) {
-  int best = 1, best_pad = 1 << 30;
-  for (int mi = 5; mi >= 1; --mi) {
+  if (Cout <= 16) return 1;
+  if (Cout <= 32) return 2;
+  int best = 3, best_pad = 1 << 30;
+  for (int mi = 5; mi >= 3; --mi) {
     int mt = 16 * mi, pad = (Cout + mt - 1) / mt * mt;
     if (pad < best_pad) {
       best_pad = pad;

@@ -56,6 +56,11 @@ __device__ __forceinline__ void wg3_steps(F&& f) {
   }
 }
 
+// Lane group kq of a k-step holds pixel octet oct_of(kq) = (0, 2, 1, 3)[kq]: the two groups that share an LDS service
+// cycle (kq = 0, 1) then read x words 16 apart (disjoint bank halves) instead of 8 apart (2-way conflict).  Any
+// bijection works as long as A (dY) and B (x) agree; oct_of is its own inverse.
+__device__ __forceinline__ int oct_of(int kq) { return ((kq & 1) << 1) | (kq >> 1); }
+
 __device__ __forceinline__ unsigned split_word(float v) {  // {hi16, lo16}
   __bf16 h = (__bf16)v;
   __bf16 l = (__bf16)(v - (float)h);
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     if (n > N - 1) n = N - 1;
     const int ci = n / KK, rem = n - ci * KK;
     const int kh = rem / KS, kw = rem - kh * KS;
-    lc[ni] = (ci - ci0) * PSX + kh * PWS + kw + 8 * kq;
+    lc[ni] = (ci - ci0) * PSX + kh * PWS + kw + 8 * oct_of(kq);
   }
   const int a_lane = kq * MT + l16;
 
@@ -194,8 +199,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
           lo[j] = (w0 & 0xffffu) | (w1 << 16);
         }
         db_part[i] += s;
-        dz[q * MT + co] = hi;
-        dz[4 * MT + q * MT + co] = lo;
+        dz[oct_of(q) * MT + co] = hi;       // pixel octet q is held by lane group oct_of(q)
+        dz[4 * MT + oct_of(q) * MT + co] = lo;
       }
     }
 #pragma unroll
