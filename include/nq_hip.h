@@ -168,6 +168,10 @@ int nq_tanh_out_backward(const float* dimg, const float* img, float* dconv, int6
 int nq_l2_loss(const float* pred, const float* tgt, float* loss, float* dpred, float* ws, int64_t n, int64_t mean_count,
                float gscale, nq_stream_t stream);
 
+/* Per-channel sums of an NCHW tensor, out[c] = sum_{b,h,w} x[b][c][h][w] (bias gradient of a convolution);
+ * ws: >= 64*C floats.  Deterministic. */
+int nq_channel_sum(const float* x, float* out, float* ws, int B, int C, int64_t HW, nq_stream_t stream);
+
 /* Per-frame PSNR pieces (utils.py:148-151): sse[f] = sum over one frame of (out-gt)^2, frames of frame_len floats. */
 int nq_frame_sse(const float* out, const float* gt, float* sse, int64_t frames, int64_t frame_len, nq_stream_t stream);
 

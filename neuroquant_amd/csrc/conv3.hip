@@ -8,8 +8,8 @@ int nq_conv_igemm3_k5(const float*, const void*, const float*, float*, float*, c
                       int, hipStream_t);
 int nq_conv3_nst_k3();
 int nq_conv3_nst_k5();
-int nq_conv_wgrad3_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, hipStream_t);
-int nq_conv_wgrad3_k5(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, hipStream_t);
+int nq_conv_wgrad3_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+int nq_conv_wgrad3_k5(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 }
 
 namespace {
@@ -74,12 +74,14 @@ __global__ __launch_bounds__(256) void weight_layout3_kernel(const float* __rest
 }
 
 struct Wg3Plan {
-  int mi, co_pad, n_pad, nsplit;
+  int mi, ni, co_pad, n_pad, nsplit;
 };
 inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
   Wg3Plan p;
   p.mi = pick_mi3(Cout);
-  const int mt = 16 * p.mi, nt = 384, N = Cin * k * k;
+  const int N = Cin * k * k;
+  p.ni = (N <= 64) ? 1 : 6;
+  const int mt = 16 * p.mi, nt = 64 * p.ni;
   p.co_pad = (Cout + mt - 1) / mt * mt;
   p.n_pad = (N + nt - 1) / nt * nt;
   const int tiles = (p.co_pad / mt) * (p.n_pad / nt);
@@ -175,8 +177,8 @@ int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float*
   float* slab = ws;
   float* slab_db = ws + (int64_t)p.nsplit * p.co_pad * p.n_pad;
   hipStream_t st = nq_s(stream);
-  int rc = (k == 3) ? nq_conv_wgrad3_k3(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, st)
-                    : nq_conv_wgrad3_k5(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, st);
+  int rc = (k == 3) ? nq_conv_wgrad3_k3(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, st)
+                    : nq_conv_wgrad3_k5(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, st);
   if (rc != NQ_OK) return rc;
   const int N = Cin * k * k;
   int64_t total = (int64_t)Cout * N + Cout;

@@ -312,10 +312,10 @@ int launch_wgrad3(const Wgrad3Args& a, hipStream_t st) {
 #define NQ_CAT2(a, b) a##b
 #define NQ_CAT(a, b) NQ_CAT2(a, b)
 
-// tile: MT = 16*mi_sel channels (mi_sel in 1..5), NT = 384 n-values
+// tile: MT = 16*mi_sel channels (mi_sel in 1..5), NT = 64*ni_sel n-values (ni_sel = 6, or 1 for C_in*k*k <= 64)
 extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, float* slab, float* slab_db, int B, int Cin,
                                                 int H, int W, int Cout, int co_pad, int n_pad, int nsplit, int mi_sel,
-                                                hipStream_t st) {
+                                                int ni_sel, hipStream_t st) {
   Wgrad3Args a;
   a.x = x; a.dy = dy; a.slab = slab; a.slab_db = slab_db;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.N = Cin * KK;
@@ -323,6 +323,16 @@ extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, 
   a.segs_x = (W + SEG - 1) / SEG;
   a.nseg = a.segs_x * H * B;
   a.nsplit = nsplit;
+  if (ni_sel == 1) {
+    switch (mi_sel) {
+      case 1: return launch_wgrad3<1, 1>(a, st);
+      case 2: return launch_wgrad3<2, 1>(a, st);
+      case 3: return launch_wgrad3<3, 1>(a, st);
+      case 4: return launch_wgrad3<4, 1>(a, st);
+      case 5: return launch_wgrad3<5, 1>(a, st);
+      default: return NQ_ERR_UNSUPPORTED;
+    }
+  }
   switch (mi_sel) {
     case 1: return launch_wgrad3<1, 6>(a, st);
     case 2: return launch_wgrad3<2, 6>(a, st);

@@ -92,6 +92,29 @@ __global__ __launch_bounds__(1024) void frame_sse_kernel(const float* __restrict
   if (threadIdx.x == 0) sse[blockIdx.x] = s;
 }
 
+// per-channel sums of an NCHW tensor (bias gradient of a conv): stage 1 = (chunk, channel) partials, stage 2 = fixed order
+constexpr int CS_CHUNKS = 64;
+__global__ __launch_bounds__(TPB) void channel_sum_stage1(const float* __restrict__ x, float* __restrict__ ws, int B, int C,
+                                                          int64_t HW) {
+  __shared__ float red[16];
+  const int c = blockIdx.y, chunk = blockIdx.x;
+  const int64_t per = (HW + CS_CHUNKS - 1) / CS_CHUNKS, lo = chunk * per, hi = min(HW, lo + per);
+  float acc = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* p = x + ((int64_t)b * C + c) * HW;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += TPB) acc += p[i];
+  }
+  float s = nq_block_sum(acc, red);
+  if (threadIdx.x == 0) ws[c * CS_CHUNKS + chunk] = s;
+}
+__global__ void channel_sum_stage2(const float* __restrict__ ws, float* __restrict__ out, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < CS_CHUNKS; ++k) s += ws[c * CS_CHUNKS + k];
+  out[c] = s;
+}
+
 __global__ __launch_bounds__(TPB) void gather_u8_kernel(const uint8_t* __restrict__ src, const int64_t* __restrict__ idx,
                                                         float* __restrict__ dst, int64_t frame_len) {
   const int64_t f = blockIdx.y;
@@ -148,6 +171,13 @@ int nq_l2_loss(const float* pred, const float* tgt, float* loss, float* dpred, f
 int nq_frame_sse(const float* out, const float* gt, float* sse, int64_t frames, int64_t frame_len, nq_stream_t stream) {
   if (!out || !gt || !sse || frames <= 0 || frame_len <= 0) return NQ_ERR_INVALID;
   hipLaunchKernelGGL(frame_sse_kernel, dim3((unsigned)frames), dim3(1024), 0, nq_s(stream), out, gt, sse, frame_len);
+  return nq_launch_status();
+}
+
+int nq_channel_sum(const float* x, float* out, float* ws, int B, int C, int64_t HW, nq_stream_t stream) {
+  if (!x || !out || !ws || B <= 0 || C <= 0 || HW <= 0 || C > 65535) return NQ_ERR_INVALID;
+  hipLaunchKernelGGL(channel_sum_stage1, dim3(CS_CHUNKS, (unsigned)C), dim3(TPB), 0, nq_s(stream), x, ws, B, C, HW);
+  hipLaunchKernelGGL(channel_sum_stage2, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, nq_s(stream), ws, out, C);
   return nq_launch_status();
 }
 

@@ -366,6 +366,27 @@ def conv_wgrad3_raw(x, dy, cout, k, want_db):
     return dw, db
 
 
+def channel_sum(x):
+    x = _dev(x)
+    B, C = x.shape[0], x.shape[1]
+    out = torch.empty(C, device=x.device, dtype=torch.float32)
+    ws = torch.empty(64 * C, device=x.device, dtype=torch.float32)
+    L.check(L.lib().nq_channel_sum(_p(x), _p(out), _p(ws), B, C, x.numel() // (B * C), _stream()), "channel_sum")
+    return out
+
+
+def conv_wgrad_swapped3(x, dy, cout, k, want_db):
+    """Weight gradient of a conv with very few OUTPUT channels (the 3-channel head) by swapping operand roles:
+    R[ci][(co,kh,kw)] = sum_p x[ci][p] * dy[co][p + tap]  is the weight gradient of the conv  dy -> x-channels, and
+    dW[co][ci][kh][kw] = R[ci][co][K-1-kh][K-1-kw].  The big tensor (x, 242 MB) is then the un-shifted GEMM operand
+    read exactly once, only the 3-channel dy needs halo rows, and the MFMA tile is 37(->48) x 27(->64) instead of
+    3(->16) x 333(->384)."""
+    cin = x.shape[1]
+    r, _ = conv_wgrad3_raw(dy, x, cin, k, False)
+    dw = r.permute(1, 0, 2, 3).flip(2, 3).contiguous()
+    return dw, (channel_sum(dy) if want_db else None)
+
+
 def conv_wgrad_raw(x, dy, cout, k, want_db, x_gelu=False):
     B, cin, H, W = x.shape
     ws = torch.empty(L.lib().nq_conv_wgrad_ws_floats(B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
@@ -525,9 +546,12 @@ class _DecoderStackFn(Function):
         for l in range(n - 1, -1, -1):
             k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
             x_in = xs[l]
-            if spec.precision == "bf16x3" and not in_gelu and conv_wgrad3_supported(x_in.shape[0], cin, x_in.shape[2],
-                                                                                    x_in.shape[3], cout, k):
+            Bx, _, Hx, Wx = x_in.shape
+            if spec.precision == "bf16x3" and not in_gelu and conv_wgrad3_supported(Bx, cin, Hx, Wx, cout, k):
                 dw, db = conv_wgrad3_raw(x_in, dconv, cout, k, has_b)
+            elif spec.precision == "bf16x3" and not in_gelu and cout <= 4 and cin > 4 and cout * k * k <= 64 \
+                    and conv_wgrad3_supported(Bx, cout, Hx, Wx, cin, k):
+                dw, db = conv_wgrad_swapped3(x_in, dconv, cout, k, has_b)
             else:
                 dw, db = conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu)
             grads[2 * l], grads[2 * l + 1] = dw, db

@@ -252,6 +252,19 @@ def test_wgrad_bf16x3(ops, case):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
+def test_wgrad_swapped_roles_small_cout(ops):
+    """head-layer weight gradient through the role-swapped bf16x3 kernel == direct fp32 kernel == float64."""
+    g = torch.Generator().manual_seed(11)
+    B, Cin, H, W, Cout, k = 2, 37, 48, 96, 3, 3
+    x, dy = torch.randn(B, Cin, H, W, generator=g), torch.randn(B, Cout, H, W, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), dy.double(), padding=1)
+    dw, db = ops.conv_wgrad_swapped3(x.to(DEV), dy.to(DEV), Cout, k, True)
+    close(dw, ref, rtol=2e-5, atol=1e-5 * float(ref.abs().max()))
+    close(db, dy.double().sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+    dw32, db32 = ops.conv_wgrad_raw(x.to(DEV), dy.to(DEV), Cout, k, True)
+    close(dw32, ref, rtol=2e-5, atol=1e-5 * float(ref.abs().max()))
+
+
 def test_conv_is_deterministic(ops):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 20, 24, 40, generator=g).to(DEV).requires_grad_(True)
