@@ -87,14 +87,14 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 }
 
 template <int MI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_igemm3_kernel(Conv3Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_igemm3_kernel(Conv3Args a) {
   constexpr int MT = 16 * MI;
   constexpr int W_U4 = 2 * 4 * MT;            // 16-byte units per weight buffer: [plane][kq][MT]
   constexpr int WPT = (W_U4 + 255) / 256;     // per thread
 
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
-  u32x4* const patch0 = smem;                  // 2 buffers of PATCH_U4
-  u32x4* const wl0 = smem + 2 * PATCH_U4;      // 2 buffers of W_U4
+  u32x4* const patch0 = smem;                  // 1 buffer of PATCH_U4 (re-filled between two barriers per chunk)
+  u32x4* const wl0 = smem + PATCH_U4;          // 2 buffers of W_U4
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
@@ -110,9 +110,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   const int64_t w_plane_stride = (int64_t)a.co_tiles * 4 * MT;   // in 16-byte units
   const int64_t w_step_stride = 2 * w_plane_stride;
 
-  // ---- staging state ----
+  // ---- staging state: weights are prefetched TWO k-steps ahead (two register sets; an L2 round trip under load is
+  //      ~2-3 k-steps of MFMA time), the next chunk's patch three steps before it is needed ----
   float pv[IPT][8];
-  u32x4 wv[WPT];
+  u32x4 wvA[WPT], wvB[WPT];
 #define NQ3_LOAD_PATCH(CH)                                                                            \
   {                                                                                                   \
     int t_ = tid;                                                                                     \
@@ -144,21 +145,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       }                                                                                               \
     }                                                                                                 \
   }
-#define NQ3_LOAD_W(CH, ST)                                                                            \
+  // weights of global step G (= chunk*NST + step): [G][plane][tile][kq][MT]
+#define NQ3_LOAD_W(SET, G)                                                                            \
   {                                                                                                   \
-    const u32x4* __restrict__ src_ = wg + ((int64_t)(CH) * NST + (ST)) * w_step_stride + (int64_t)cot * 4 * MT; \
+    const u32x4* __restrict__ src_ = wg + (int64_t)(G) * w_step_stride + (int64_t)cot * 4 * MT;       \
     _Pragma("unroll") for (int i = 0; i < WPT; ++i) {                                                 \
       const int f_ = tid + i * 256;                                                                   \
       if (i + 1 < WPT || f_ < W_U4) {                                                                 \
         const int pl_ = f_ / (4 * MT), rem_ = f_ - pl_ * (4 * MT);                                    \
-        wv[i] = src_[pl_ * w_plane_stride + rem_];                                                    \
+        SET[i] = src_[pl_ * w_plane_stride + rem_];                                                   \
       }                                                                                               \
     }                                                                                                 \
   }
-#define NQ3_STORE_W(DST)                                                                              \
+#define NQ3_STORE_W(SET, DST)                                                                         \
   _Pragma("unroll") for (int i = 0; i < WPT; ++i) {                                                   \
     const int f_ = tid + i * 256;                                                                     \
-    if (i + 1 < WPT || f_ < W_U4) (DST)[f_] = wv[i];                                                  \
+    if (i + 1 < WPT || f_ < W_U4) (DST)[f_] = SET[i];                                                 \
   }
 
   f32x4 acc[MI][4];
@@ -172,39 +174,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
   const bool odd_tap = (kq >> 1) != 0;
   // A fragment base (16-byte units): [kq][MT] + l16
   const int a_lane = kq * MT + l16;
+  const u32x4* __restrict__ pb = patch0 + b_lane;
 
-  // ---- prologue ----
+  // ---- prologue: step 0 -> LDS buffer 0 (via set A), step 1 in flight in set B ----
   const int nchunk = a.nchunk;
+  const int G = nchunk * NST;
   NQ3_LOAD_PATCH(0)
-  NQ3_LOAD_W(0, 0)
+  NQ3_LOAD_W(wvA, 0)
+  if (G > 1) {
+    NQ3_LOAD_W(wvB, 1)
+  }
   NQ3_STORE_PATCH(patch0)
-  NQ3_STORE_W(wl0)
+  NQ3_STORE_W(wvA, wl0)
   __syncthreads();
 
-  int wbuf = 0;
-  for (int ch = 0; ch < nchunk; ++ch) {
-    const u32x4* __restrict__ pb = patch0 + (ch & 1) * PATCH_U4 + b_lane;
+  // one chunk; PAR = parity of its first global step: LDS buffer (g&1) holds step g, register set B/A ((g+1)&1 = 1/0)
+  // holds step g+1, the loads of step g+2 are issued into the other set at the start of step g
+  auto run_chunk = [&](auto par_c, int ch) {
+    constexpr int PAR = decltype(par_c)::value;
+    const int g0 = ch * NST;
     steps3<0, NST>([&](auto st_c) {
       constexpr int st = decltype(st_c)::value;
-      constexpr bool last_step = (st == NST - 1);
-      const bool more_w = !(last_step && ch + 1 == nchunk);
-      const bool new_patch = last_step && (ch + 1 < nchunk);
-      if (more_w) {
-        if constexpr (last_step) {
-          NQ3_LOAD_W(ch + 1, 0)
+      constexpr int gp = (PAR + st) & 1;  // parity of the global step
+      const int g = g0 + st;
+      if (g + 2 < G) {
+        if constexpr (gp == 0) {
+          NQ3_LOAD_W(wvA, g + 2)
         } else {
-          NQ3_LOAD_W(ch, st + 1)
+          NQ3_LOAD_W(wvB, g + 2)
         }
       }
-      if (new_patch) {
-        NQ3_LOAD_PATCH(ch + 1)
+      constexpr int pst = (NST >= 3) ? NST - 3 : 0;
+      if constexpr (st == pst) {
+        if (ch + 1 < nchunk) {
+          NQ3_LOAD_PATCH(ch + 1)
+        }
       }
       // taps of this step: even lane groups -> tap 2*st, odd -> tap 2*st+1 (clamped; its weights are zero when padded)
       constexpr int te = 2 * st, to_ = (2 * st + 1 < KK) ? 2 * st + 1 : KK - 1;
       constexpr int off_e = (te / KS) * PW + (te % KS), off_o = (to_ / KS) * PW + (to_ % KS);
       const u32x4* __restrict__ pbt = pb + (odd_tap ? off_o : off_e);
-      const u32x4* __restrict__ wb = wl0 + wbuf * W_U4 + a_lane;
-      // B fragments of the wave's 4 pixel blocks (rows 2w, 2w+1 x 2 column halves), hi and lo planes
+      const u32x4* __restrict__ wb = wl0 + gp * W_U4 + a_lane;
       bf16x8 bh[4], bl[4];
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
@@ -227,17 +237,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
           acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nb], acc[mi][nb], 0, 0, 0);
         }
       });
-      if (more_w) {
-        u32x4* wdst = wl0 + (wbuf ^ 1) * W_U4;
-        NQ3_STORE_W(wdst)
+      if (g + 1 < G) {  // publish step g+1 (loaded one step ago) into the other LDS buffer
+        u32x4* wdst = wl0 + (gp ^ 1) * W_U4;
+        if constexpr (gp == 0) {
+          NQ3_STORE_W(wvB, wdst)
+        } else {
+          NQ3_STORE_W(wvA, wdst)
+        }
       }
-      if (new_patch) {
-        u32x4* pdst = patch0 + ((ch + 1) & 1) * PATCH_U4;
-        NQ3_STORE_PATCH(pdst)
+      if constexpr (st == NST - 1) {
+        if (ch + 1 < nchunk) {
+          __syncthreads();  // every wave is done with the current patch
+          NQ3_STORE_PATCH(patch0)
+        }
       }
       __syncthreads();
-      wbuf ^= 1;
     });
+  };
+  for (int ch = 0; ch < nchunk; ch += 2) {
+    run_chunk(std::integral_constant<int, 0>{}, ch);
+    if (ch + 1 < nchunk) run_chunk(std::integral_constant<int, (NST & 1)>{}, ch + 1);
   }
 #undef NQ3_LOAD_PATCH
 #undef NQ3_STORE_PATCH
@@ -310,7 +329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 template <int MI>
 int launch_igemm3(const Conv3Args& a, int tiles, hipStream_t st) {
   constexpr int MT = 16 * MI;
-  size_t lds = (size_t)(2 * PATCH_U4 + 2 * 2 * 4 * MT) * 16;
+  size_t lds = (size_t)(PATCH_U4 + 2 * 2 * 4 * MT) * 16;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm3_kernel<MI>), hipFuncAttributeMaxDynamicSharedMemorySize,

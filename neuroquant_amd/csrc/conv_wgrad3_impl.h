@@ -68,7 +68,7 @@ __device__ __forceinline__ unsigned split_word(float v) {  // {hi16, lo16}
 }
 
 template <int MI, int NI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv_wgrad3_kernel(Wgrad3Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad3_kernel(Wgrad3Args a) {
   constexpr int MT = 16 * MI, NT = 64 * NI;
   constexpr int CIT = (NT + KK - 2) / KK + 1;
   constexpr int DZ_U4 = 2 * 4 * MT;              // 16-byte units: [plane][kq][MT]
