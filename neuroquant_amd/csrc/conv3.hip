@@ -93,23 +93,37 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
   return p;
 }
 
+// Fixed-order reduction of the split slabs: a workgroup owns 256/SG consecutive outputs, split group g adds slabs
+// g, g+SG, g+2SG, ... in order, and the SG partial sums are combined in LDS in index order -> run-to-run identical.
+template <int SG>
 __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ slab_db,
                                                             float* __restrict__ dw, float* __restrict__ db, int Cout, int N,
                                                             int co_pad, int n_pad, int nsplit) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  constexpr int OG = 256 / SG;
+  __shared__ float part[SG][OG];
+  const int o = threadIdx.x % OG, g = threadIdx.x / OG;
+  const int64_t i = (int64_t)blockIdx.x * OG + o;
   const int64_t total = (int64_t)Cout * N;
+  float s = 0.f;
   if (i < total) {
-    int co = (int)(i / N), n = (int)(i - (int64_t)co * N);
+    const int co = (int)(i / N), n = (int)(i - (int64_t)co * N);
     const float* p = slab + (int64_t)co * n_pad + n;
     const int64_t stride = (int64_t)co_pad * n_pad;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += p[k * stride];
-    dw[i] = s;
+#pragma unroll 4
+    for (int k = g; k < nsplit; k += SG) s += p[k * stride];
   } else if (db && i < total + Cout) {
-    int co = (int)(i - total);
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += slab_db[(int64_t)k * co_pad + co];
-    db[co] = s;
+    const int co = (int)(i - total);
+#pragma unroll 4
+    for (int k = g; k < nsplit; k += SG) s += slab_db[(int64_t)k * co_pad + co];
+  }
+  part[g][o] = s;
+  __syncthreads();
+  if (g == 0) {
+    float t = part[0][o];
+#pragma unroll
+    for (int j = 1; j < SG; ++j) t += part[j][o];
+    if (i < total) dw[i] = t;
+    else if (db && i < total + Cout) db[(int)(i - total)] = t;
   }
 }
 
@@ -182,8 +196,13 @@ int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float*
   if (rc != NQ_OK) return rc;
   const int N = Cin * k * k;
   int64_t total = (int64_t)Cout * N + Cout;
-  hipLaunchKernelGGL(wgrad3_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slab, slab_db, dw, db, Cout,
-                     N, p.co_pad, p.n_pad, p.nsplit);
+  if (total < 65536 && p.nsplit >= 16) {
+    hipLaunchKernelGGL(wgrad3_reduce_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, slab, slab_db, dw, db,
+                       Cout, N, p.co_pad, p.n_pad, p.nsplit);
+  } else {
+    hipLaunchKernelGGL(wgrad3_reduce_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, slab, slab_db, dw, db,
+                       Cout, N, p.co_pad, p.n_pad, p.nsplit);
+  }
   return nq_launch_status();
 }
 

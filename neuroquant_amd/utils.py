@@ -131,8 +131,11 @@ class CacheLoader:
         self.epoch += 1
         per = self.bs // self.world
         dev = self.cache.frames.device
-        for row in sel:
-            idx = row[self.rank * per:(self.rank + 1) * per].to(dev)
+        # this rank's slice of every batch goes to the device ONCE per epoch: a per-batch pageable H2D copy would
+        # block the host on the stream every iteration
+        mine = sel[:, self.rank * per:(self.rank + 1) * per].contiguous().to(dev)
+        for i in range(mine.shape[0]):
+            idx = mine[i]
             yield {'img': self.cache.batch(idx), 'idx': idx, 'norm_idx': idx.float() / self.n_total}
 
 
