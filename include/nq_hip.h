@@ -136,12 +136,14 @@ int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y
  *   nq_conv3_weight_bytes : size of the pre-split operand of a (Cin -> Cout, k) convolution
  *   nq_weight_layout3     : builds it from the OIHW weight w; transposed = 1 builds the operand of the data gradient
  *                           (then Cin/Cout are those of the gradient convolution: Cin = w's C_out, Cout = w's C_in)
- *   nq_conv_forward3      : same contract as nq_conv_forward (epilogues, zprev), no split-K workspace */
+ *   nq_conv_forward3      : same contract as nq_conv_forward (epilogues, zprev); ws = nq_conv_forward3_ws_floats
+ *                           floats (0 -> may be NULL): deep low-resolution layers are split over channel chunks */
 int nq_conv3_supported(int B, int Cin, int H, int W, int Cout, int k);
+int64_t nq_conv_forward3_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
 int64_t nq_conv3_weight_bytes(int Cin, int Cout, int k);
 int nq_weight_layout3(const float* w, void* wt3, int Cin, int Cout, int k, int transposed, nq_stream_t stream);
-int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* y, float* z, const float* zprev, int B, int Cin,
-                     int H, int W, int Cout, int k, int r, int epilogue, nq_stream_t stream);
+int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* y, float* z, const float* zprev, float* ws, int B,
+                     int Cin, int H, int W, int Cout, int k, int r, int epilogue, nq_stream_t stream);
 
 /* bf16x3 variant of nq_conv_wgrad (same contract, x_gelu not offered): */
 int nq_conv_wgrad3_supported(int B, int Cin, int H, int W, int Cout, int k);

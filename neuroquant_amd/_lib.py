@@ -48,7 +48,8 @@ def _load():
     sig("nq_conv3_supported", I, I, I, I, I, I, I)
     sig("nq_conv3_weight_bytes", L, I, I, I)
     sig("nq_weight_layout3", I, P, P, I, I, I, I, P)
-    sig("nq_conv_forward3", I, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P)
+    sig("nq_conv_forward3_ws_floats", L, I, I, I, I, I, I)
+    sig("nq_conv_forward3", I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P)
     sig("nq_conv_wgrad3_supported", I, I, I, I, I, I, I)
     sig("nq_conv_wgrad3_ws_floats", L, I, I, I, I, I, I)
     sig("nq_conv_wgrad3", I, P, P, P, P, P, I, I, I, I, I, I, P)
@@ -67,7 +68,7 @@ EXPORTS = (
     "nq_abi_version", "nq_error_string", "nq_scale_init_max", "nq_uaq_forward", "nq_uaq_backward",
     "nq_adaround_init", "nq_adaround_forward", "nq_adaround_backward", "nq_reduce_ws_floats", "nq_round_loss", "nq_round_loss_backward",
     "nq_adam_step", "nq_fwht", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
-    "nq_conv3_supported", "nq_conv3_weight_bytes", "nq_weight_layout3", "nq_conv_forward3",
+    "nq_conv3_supported", "nq_conv3_weight_bytes", "nq_weight_layout3", "nq_conv_forward3_ws_floats", "nq_conv_forward3",
     "nq_conv_wgrad3_supported", "nq_conv_wgrad3_ws_floats", "nq_conv_wgrad3",
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",
     "nq_channel_sum", "nq_frame_sse", "nq_gather_frames_u8",

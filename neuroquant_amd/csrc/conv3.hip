@@ -3,9 +3,10 @@
 
 extern "C" {
 int nq_conv_igemm3_k3(const float*, const void*, const float*, float*, float*, const float*, int, int, int, int, int, int, int,
-                      int, hipStream_t);
+                      int, int, int, float*, hipStream_t);
 int nq_conv_igemm3_k5(const float*, const void*, const float*, float*, float*, const float*, int, int, int, int, int, int, int,
-                      int, hipStream_t);
+                      int, int, int, float*, hipStream_t);
+int nq_conv_splitk_finish(const float*, const float*, float*, float*, const float*, int, int, int, int, int, int, int, hipStream_t);
 int nq_conv3_nst_k3();
 int nq_conv3_nst_k5();
 int nq_conv_wgrad3_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, hipStream_t);
@@ -73,6 +74,28 @@ __global__ __launch_bounds__(256) void weight_layout3_kernel(const float* __rest
   out[base + plane_stride] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
 }
 
+// split-K of the forward / data-gradient kernel over 16-channel chunks when the pixel x channel grid alone cannot fill
+// the chip (deep, low-resolution layers): ~512 workgroups, every split non-empty
+struct Fwd3Plan {
+  int mi, nsplit, per;
+  int64_t wgs;
+};
+inline Fwd3Plan plan_fwd3(int B, int Cin, int H, int W, int Cout) {
+  Fwd3Plan p;
+  p.mi = pick_mi3(Cout);
+  p.wgs = (int64_t)((W + 31) / 32) * ((H + 7) / 8) * ((Cout + 16 * p.mi - 1) / (16 * p.mi)) * B;
+  const int nchunk = (Cin + CC - 1) / CC;
+  p.nsplit = 1;
+  p.per = nchunk;
+  if (p.wgs < 256) {
+    int want = (int)((512 + p.wgs - 1) / p.wgs);
+    if (want > nchunk) want = nchunk;
+    p.per = (nchunk + want - 1) / want;
+    p.nsplit = (nchunk + p.per - 1) / p.per;
+  }
+  return p;
+}
+
 struct Wg3Plan {
   int mi, ni, co_pad, n_pad, nsplit;
 };
@@ -133,9 +156,14 @@ extern "C" {
 
 int nq_conv3_supported(int B, int Cin, int H, int W, int Cout, int k) {
   if (!(k == 3 || k == 5) || B <= 0 || Cin <= 0 || Cout <= 4 || Cin <= 4) return 0;
-  const int mi = pick_mi3(Cout);
-  const int64_t wgs = (int64_t)((W + 31) / 32) * ((H + 7) / 8) * ((Cout + 16 * mi - 1) / (16 * mi)) * B;
-  return wgs >= 256;  // smaller grids stay on the fp32 split-K kernel
+  const Fwd3Plan p = plan_fwd3(B, Cin, H, W, Cout);
+  return p.wgs * p.nsplit >= 192;  // still smaller grids stay on the fp32 split-K kernel
+}
+
+int64_t nq_conv_forward3_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
+  if (!(k == 3 || k == 5) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  const Fwd3Plan p = plan_fwd3(B, Cin, H, W, Cout);
+  return p.nsplit > 1 ? (int64_t)p.nsplit * B * Cout * H * W : 0;
 }
 
 int64_t nq_conv3_weight_bytes(int Cin, int Cout, int k) {
@@ -157,23 +185,26 @@ int nq_weight_layout3(const float* w, void* wt3, int Cin, int Cout, int k, int t
   return nq_launch_status();
 }
 
-int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* y, float* z, const float* zprev, int B, int Cin,
-                     int H, int W, int Cout, int k, int r, int epilogue, nq_stream_t stream) {
+int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* y, float* z, const float* zprev, float* ws, int B,
+                     int Cin, int H, int W, int Cout, int k, int r, int epilogue, nq_stream_t stream) {
   if (!x || !wt3 || (!y && epilogue != NQ_EPI_PS) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
   if (!(k == 3 || k == 5)) return NQ_ERR_UNSUPPORTED;
   if (epilogue < 0 || epilogue > NQ_EPI_DGRAD_GELU) return NQ_ERR_INVALID;
   if ((epilogue == NQ_EPI_PS_GELU || epilogue == NQ_EPI_PS) && (!z || r <= 0 || Cout % (r * r) != 0)) return NQ_ERR_INVALID;
   if (epilogue == NQ_EPI_DGRAD_GELU && (!zprev || r <= 0 || H % r != 0 || W % r != 0)) return NQ_ERR_INVALID;
   if (B > 65535) return NQ_ERR_UNSUPPORTED;
-  const int mi = pick_mi3(Cout);
+  const Fwd3Plan p = plan_fwd3(B, Cin, H, W, Cout);
+  if (p.nsplit > 1 && !ws) return NQ_ERR_INVALID;
   hipStream_t st = nq_s(stream);
-  if (k == 3) return nq_conv_igemm3_k3(x, wt3, bias, y, z, zprev, B, Cin, H, W, Cout, r, epilogue, mi, st);
-  return nq_conv_igemm3_k5(x, wt3, bias, y, z, zprev, B, Cin, H, W, Cout, r, epilogue, mi, st);
+  int rc = (k == 3) ? nq_conv_igemm3_k3(x, wt3, bias, y, z, zprev, B, Cin, H, W, Cout, r, epilogue, p.mi, p.nsplit, p.per, ws, st)
+                    : nq_conv_igemm3_k5(x, wt3, bias, y, z, zprev, B, Cin, H, W, Cout, r, epilogue, p.mi, p.nsplit, p.per, ws, st);
+  if (rc != NQ_OK || p.nsplit == 1) return rc;
+  return nq_conv_splitk_finish(ws, bias, y, z, zprev, B, H, W, Cout, r, epilogue, p.nsplit, st);
 }
 
 int nq_conv_wgrad3_supported(int B, int Cin, int H, int W, int Cout, int k) {
   if (!(k == 3 || k == 5) || B <= 0 || Cin <= 0 || Cout <= 4) return 0;
-  return (int64_t)((W + 31) / 32) * H * B >= 512;  // enough 32-pixel segments to fill the chip
+  return (int64_t)((W + 31) / 32) * H * B >= 128;  // enough 32-pixel segments to split over
 }
 
 int64_t nq_conv_wgrad3_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {

@@ -45,6 +45,8 @@ struct Conv3Args {
   float* z;
   const float* zprev;
   int B, Cin, H, W, Cout, r, epi, tiles_x, nchunk, co_tiles;
+  int nsplit, per_split;  // split-K over channel chunks: blockIdx.z = b*nsplit + split, chunks [split*per, +per)
+  float* slab;            // [nsplit][B][Cout][H][W] raw partial sums when nsplit > 1 (nq_conv_splitk_finish adds them)
 };
 
 constexpr int KS = NQ_KS;
@@ -101,14 +103,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
   const int x0 = tile_x * TW, y0 = tile_y * TH;
   const int cot = blockIdx.y, co0 = cot * MT;
-  const int b = blockIdx.z;
-  const int H = a.H, W = a.W, Cin = a.Cin;
+  const int b = blockIdx.z / a.nsplit, split = blockIdx.z - b * a.nsplit;
+  const int c_lo = split * a.per_split;  // first chunk of this split
+  const int H = a.H, W = a.W, Cin = a.Cin - c_lo * CC;  // channels from this split's first one on
   const int64_t HW = (int64_t)H * W;
-  const float* __restrict__ xb = a.x + (int64_t)b * Cin * HW;
+  const float* __restrict__ xb = a.x + ((int64_t)b * a.Cin + (int64_t)c_lo * CC) * HW;
   // weights of (chunk c, step s): base + ((c*NST + s) * co_tiles*2 ... see nq_weight_layout3: [c][s][plane][tile][kq][MT]
-  const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(a.wt3);
   const int64_t w_plane_stride = (int64_t)a.co_tiles * 4 * MT;   // in 16-byte units
   const int64_t w_step_stride = 2 * w_plane_stride;
+  const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(a.wt3) + (int64_t)c_lo * NST * w_step_stride;
 
   // ---- staging state: weights are prefetched TWO k-steps ahead (two register sets; an L2 round trip under load is
   //      ~2-3 k-steps of MFMA time), the next chunk's patch three steps before it is needed ----
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const u32x4* __restrict__ pb = patch0 + b_lane;
 
   // ---- prologue: step 0 -> LDS buffer 0 (via set A), step 1 in flight in set B ----
-  const int nchunk = a.nchunk;
+  const int nchunk = min(a.per_split, a.nchunk - c_lo);
   const int G = nchunk * NST;
   NQ3_LOAD_PATCH(0)
   NQ3_LOAD_W(wvA, 0)
@@ -264,8 +267,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef NQ3_STORE_W
 
   // ---- epilogue (same element mapping as conv_igemm_impl.h; nb = (row 2w + nb/2, column half nb%2)) ----
-  const int Cout = a.Cout, epi = a.epi, r = a.r, rr = a.r * a.r;
+  const int Cout = a.Cout, r = a.r, rr = a.r * a.r;
   const int cob = co0 + 4 * kq;
+  if (a.nsplit > 1) {  // raw partial sums of this split; bias / activation happen in the finish kernel
+    float* __restrict__ ys = a.slab + ((int64_t)split * a.B + b) * Cout * HW;
+    steps3<0, MI>([&](auto mi_c) {
+      constexpr int mi = decltype(mi_c)::value;
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int py = y0 + 2 * wave + (nb >> 1), px = x0 + (nb & 1) * 16 + l16;
+        if (py >= H || px >= W) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int cc = cob + mi * 16 + reg;
+          if (cc < Cout) ys[(int64_t)cc * HW + (int64_t)py * W + px] = acc[mi][nb][reg];
+        }
+      }
+    });
+    return;
+  }
+  const int epi = a.epi;
   steps3<0, MI>([&](auto mi_c) {
     constexpr int mi = decltype(mi_c)::value;
     const int co = cob + mi * 16;  // first of the lane's 4 channels (multiple of 4)
@@ -337,7 +358,8 @@ int launch_igemm3(const Conv3Args& a, int tiles, hipStream_t st) {
       return NQ_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL(conv_igemm3_kernel<MI>, dim3((unsigned)tiles, (unsigned)a.co_tiles, (unsigned)a.B), dim3(256), lds, st, a);
+  hipLaunchKernelGGL(conv_igemm3_kernel<MI>, dim3((unsigned)tiles, (unsigned)a.co_tiles, (unsigned)(a.B * a.nsplit)), dim3(256),
+                     lds, st, a);
   return nq_launch_status();
 }
 
@@ -348,8 +370,9 @@ int launch_igemm3(const Conv3Args& a, int tiles, hipStream_t st) {
 
 extern "C" int NQ_CAT(nq_conv_igemm3_k, NQ_KS)(const float* x, const void* wt3, const float* bias, float* y, float* z,
                                                 const float* zprev, int B, int Cin, int H, int W, int Cout, int r, int epi,
-                                                int mi_sel, hipStream_t st) {
+                                                int mi_sel, int nsplit, int per_split, float* slab, hipStream_t st) {
   Conv3Args a;
+  a.nsplit = nsplit; a.per_split = per_split; a.slab = slab;
   a.x = x; a.wt3 = wt3; a.bias = bias; a.y = y; a.z = z; a.zprev = zprev;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.r = r; a.epi = epi;
   a.tiles_x = (W + TW - 1) / TW;

@@ -344,9 +344,11 @@ def conv3_forward_raw(x, wt3, bias, cout, k, epilogue, r, zprev=None):
         y = torch.empty((B, cout * r * r, H // r, W // r), device=x.device, dtype=torch.float32)
     else:
         y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+    nws = L.lib().nq_conv_forward3_ws_floats(B, cin, H, W, cout, k)
+    ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
     _timed(("conv_igemm3", k, cin, cout, H, W, B, epilogue),
-           lambda: L.check(L.lib().nq_conv_forward3(_p(x), _p(wt3), _p(bias), _p(y), _p(z), _p(zprev), B, cin, H, W, cout, k,
-                                                    r, epilogue, _stream()), "conv_forward3"))
+           lambda: L.check(L.lib().nq_conv_forward3(_p(x), _p(wt3), _p(bias), _p(y), _p(z), _p(zprev), _p(ws), B, cin, H, W,
+                                                    cout, k, r, epilogue, _stream()), "conv_forward3"))
     return y, z
 
 

@@ -203,10 +203,12 @@ def test_conv_forward_backward(ops, case):
 
 @pytest.mark.parametrize("case", [(2, 44, 24, 96, 148, 5, "psgelu", 2), (2, 148, 24, 96, 44, 5, "plain", 1),
                                   (3, 53, 17, 70, 176, 5, "psgelu", 2), (2, 64, 40, 80, 848, 5, "psgelu", 4),
-                                  (2, 20, 33, 100, 96, 3, "tanh", 1), (4, 9, 16, 64, 36, 3, "dgrad", 2)])
+                                  (2, 20, 33, 100, 96, 3, "tanh", 1), (4, 9, 16, 64, 36, 3, "dgrad", 2),
+                                  (2, 848, 40, 80, 64, 5, "dgrad", 4), (1, 200, 20, 40, 64, 5, "plain", 1)])
 def test_conv_bf16x3(ops, case):
     """bf16x3 kernel (split operands on the BF16 matrix pipe) vs float64: error stays at the fp32 level (a few 1e-6
-    relative to the output scale), forward epilogues and the data-gradient operand (transposed=True) included."""
+    relative to the output scale), forward epilogues and the data-gradient operand (transposed=True) included.  Grids
+    below 256 workgroups (all but the full-size layers) also exercise the split-K path + finish kernel."""
     B, Cin, H, W, Cout, k, epi, r = case
     g = torch.Generator().manual_seed(sum(v for v in case if isinstance(v, int)))
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -235,7 +237,7 @@ def test_conv_bf16x3(ops, case):
     close(y, ref, rtol=2e-5, atol=3e-5)
 
 
-@pytest.mark.parametrize("case", [(2, 44, 24, 96, 148, 5), (1, 53, 17, 70, 176, 5), (2, 64, 12, 40, 848, 5),
+@pytest.mark.parametrize("case", [(2, 44, 24, 96, 148, 5), (1, 53, 17, 70, 176, 5), (2, 64, 12, 40, 848, 5), (2, 64, 40, 80, 848, 5),
                                   (2, 20, 33, 100, 96, 3), (3, 9, 16, 64, 36, 3), (1, 37, 40, 64, 12, 3)])
 def test_wgrad_bf16x3(ops, case):
     """bf16x3 weight/bias gradient vs float64 (error at the fp32 level relative to the gradient scale); deterministic."""
