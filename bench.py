@@ -31,7 +31,12 @@ HNERV_3M = dict(crop_h=640, crop_w=1280, diff_enc=False, stage_block=1, enc_stri
                 dec_kernels=[1, 3, 5, 5, 5], dec_strides=[5, 4, 4, 2, 2], dec_norm="none", dec_acts="gelu",
                 out_bias="tanh")
 BITS = [6, 5, 4, 5, 5, 6, 6]
-PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, fp32-input MFMA
+# /opt/skills/guides/MI355X_MICROARCH.md, Matrix cores: fp32-input MFMA 157.3 TF; dense BF16 MFMA ~2.5 PF.  The bf16x3
+# kernels spend three BF16 MFMAs per fp32-equivalent product (hi*hi + hi*lo + lo*hi), so their ceiling in ALGORITHMIC
+# (fp32-equivalent) FLOP/s is 2500/3.
+PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 FLAGS = dict(weight=0.01, b_range=(20, 2), lr=0.003)
 
 
@@ -156,9 +161,13 @@ def main():
             traffic = json.load(open(tpath)).get(f'{dom["kernel"]}_k{dom["k"]}_{dom["cin"]}_{dom["cout"]}', {}).get("bytes")
         except Exception:
             traffic = None
+    is3 = dom["kernel"].endswith("3")
+    peak = PEAK_BF16X3_TFLOPS if is3 else PEAK_F32_MFMA_TFLOPS
     roofline = dict(bound="mfma", kernel=f'{dom["kernel"]} k{dom["k"]} {dom["cin"]}->{dom["cout"]} {dom["H"]}x{dom["W"]}',
-                    achieved=round(dom["tflops"], 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
-                    frac=round(dom["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), traffic=traffic,
+                    achieved=round(dom["tflops"], 2), peak=round(peak, 1), unit="TFLOP/s",
+                    frac=round(dom["tflops"] / peak, 4), traffic=traffic,
+                    peak_basis=("dense BF16 MFMA 2500 TF / 3 products per fp32-equivalent FLOP (bf16x3)" if is3
+                                else "fp32-input MFMA 157.3 TF"),
                     avg_launch_ms=round(dom["avg_ms"], 4), gflop_per_launch=round(dom["gflop_per_launch"], 2),
                     all_conv_tflops=round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
                     conv_share_of_step=round(conv_ms / (elapsed * 1e3), 3))
@@ -179,7 +188,9 @@ def main():
         "metric": "calibration iters/sec (HNeRV Bunny 1280x640, 21k iters) + final PSNR vs ref",
         "value": round(value, 3), "unit": "it/s (B=2 frames per iteration-equivalent, summed over GPUs)",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 operands split into bf16 hi+lo, 3 BF16 MFMAs per product, fp32 accumulate (bf16x3); fp32 MFMA on small layers",
+        "data": "synthetic",
         "config": {"workload": "HNeRV Bunny_1280x640_3M, channel_wise, bits 6 5 4 5 5 6 6, phase-2 (AdaRound) iteration",
                    "per_gpu_batch": B, "global_batch": gB, "frames": n_frames, "avg_bits": avg_bits,
                    "parallelism": f"dp{world}"},

@@ -110,7 +110,9 @@ int nq_conv_operand_dims(int Cin, int Cout, int k, int* krows, int* ld);
  *   stride 1, padding k/2, x (B,Cin,H,W), wt = wt_fwd layout from nq_weight_layouts, bias (Cout) or NULL.
  *   epilogue NQ_EPI_PLAIN     : y (B,Cout,H,W) = conv + bias
  *            NQ_EPI_PS_GELU   : PixelShuffle(r) + exact-erf GELU (quant_block.py:31-35, _layers.py:20-36):
- *                               z (B,Cout/r^2,H*r,W*r) = shuffled pre-activation, y = gelu(z)
+ *                               with v = shuffled conv+bias, (B,Cout/r^2,H*r,W*r): y = gelu(v) and z = gelu'(v), the
+ *                               derivative saved for the backward pass (one erf serves both; no backward kernel
+ *                               evaluates erf/exp again)
  *            NQ_EPI_TANH      : y = tanh(conv+bias)*0.5+0.5 (OutImg, _layers.py:10-16)
  * The data gradient of a convolution is the same call with wt = wt_bwd and Cin/Cout swapped.
  * ws: scratch of >= nq_conv_forward_ws_floats(...) floats (may be NULL when that is 0): layers with few pixel
@@ -118,12 +120,12 @@ int nq_conv_operand_dims(int Cin, int Cout, int k, int* krows, int* ld);
 #define NQ_EPI_PLAIN 0
 #define NQ_EPI_PS_GELU 1
 #define NQ_EPI_TANH 2
-#define NQ_EPI_PS 3         /* PixelShuffle(r) only: z = shuffled pre-activation; the consumer applies GELU on load */
-#define NQ_EPI_DGRAD_GELU 4 /* data gradient: y = conv * gelu'(zprev) (zprev (B,Cout,H,W)), stored PixelUnshuffle(r)-ed, i.e.
-                             * as the (B,Cout*r*r,H/r,W/r) output gradient of the convolution below */
+#define NQ_EPI_PS 3         /* PixelShuffle(r) only: z = shuffled conv+bias (no activation) */
+#define NQ_EPI_DGRAD_GELU 4 /* data gradient: y = conv * zprev, zprev (B,Cout,H,W) = the z a NQ_EPI_PS_GELU forward saved
+                             * (= gelu' of the pre-activation), stored PixelUnshuffle(r)-ed, i.e. as the
+                             * (B,Cout*r*r,H/r,W/r) output gradient of the convolution below */
 int64_t nq_conv_forward_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
-/* in_gelu != 0: x holds pre-activations and exact GELU is applied while the input tile is staged (the activation
- * tensor itself is never written). */
+/* in_gelu != 0: x holds pre-activations and exact GELU is applied while the input tile is staged. */
 int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y, float* z, float* ws, int B, int Cin, int H,
                     int W, int Cout, int k, int krows, int ld, int r, int epilogue, int in_gelu, const float* zprev,
                     nq_stream_t stream);
@@ -158,7 +160,8 @@ int64_t nq_conv_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
 int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                   int k, int x_gelu, nq_stream_t stream);
 
-/* Backward of PixelShuffle(r)+GELU: dconv (B,C*r*r,H,W) = unshuffle(da * gelu'(z)), da and z are (B,C,H*r,W*r). */
+/* Backward of PixelShuffle(r)+GELU: dconv (B,C*r*r,H,W) = unshuffle(da * z), da and z (B,C,H*r,W*r), z = the saved
+ * derivative output of a NQ_EPI_PS_GELU forward. */
 int nq_ps_gelu_backward(const float* da, const float* z, float* dconv, int B, int C, int H, int W, int r,
                         nq_stream_t stream);
 

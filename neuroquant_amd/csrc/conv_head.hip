@@ -7,7 +7,7 @@
 //   head_fwd   : thread = 4 consecutive pixels, input patch staged in LDS per 4-channel chunk, weights via
 //                scalar loads, fused bias + tanh*0.5+0.5 (OutImg, models/_layers.py:10-16)
 //   head_dgrad : thread = 4 pixels, the C_out x k x (4+k-1) neighbourhood of dY lives in registers, loop over C_in,
-//                fused gelu'(z) and PixelUnshuffle store (same contract as NQ_EPI_DGRAD_GELU)
+//                fused multiply by the saved gelu'(z) and PixelUnshuffle store (same contract as NQ_EPI_DGRAD_GELU)
 // (The weight gradient of the head stays on the MFMA split-K kernel of conv_wgrad_impl.h: a VALU variant with one
 //  thread per (ci,kh,kw) was measured slower, 0.66-0.80 ms vs 0.56 ms.)
 // Roofline: HBM (8 TB/s spec / 6.3 TB/s achievable); algorithmic bytes = 4*B*H*W*(C_in + C_out) per launch
@@ -17,12 +17,6 @@
 namespace {
 
 constexpr int MAXCO = 4;
-
-__device__ __forceinline__ float gelu_grad_h(float v) {
-  float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-  float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
-  return cdf + v * pdf;
-}
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int KS>
@@ -160,11 +154,11 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
     if (zprev) {
       if (full && (W & 3) == 0) {
         const float4 zv = *reinterpret_cast<const float4*>(zprev + zi);
-        acc[0] *= gelu_grad_h(zv.x); acc[1] *= gelu_grad_h(zv.y); acc[2] *= gelu_grad_h(zv.z); acc[3] *= gelu_grad_h(zv.w);
+        acc[0] *= zv.x; acc[1] *= zv.y; acc[2] *= zv.z; acc[3] *= zv.w;
       } else {
 #pragma unroll
         for (int p = 0; p < 4; ++p)
-          if (gx0 + p < W) acc[p] *= gelu_grad_h(zprev[zi + p]);
+          if (gx0 + p < W) acc[p] *= zprev[zi + p];
       }
     }
     if (r == 1) {

@@ -70,12 +70,6 @@ __device__ __forceinline__ void steps3(F&& f) {
   }
 }
 
-__device__ __forceinline__ float gelu3(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu3_grad(float v) {
-  float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-  float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
-  return cdf + v * pdf;
-}
 
 // split 8 floats into packed bf16 hi / lo vectors (round-to-nearest-even both times)
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
@@ -287,6 +281,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     return;
   }
   const int epi = a.epi;
+  if (epi == NQ_EPI_DGRAD_GELU) {
+    // data gradient w.r.t. the pre-activation below: acc * gelu'(z) (zprev = the derivative saved by the forward
+    // epilogue, same NCHW layout as this conv's output), stored un-shuffled: channel c*r*r + (y%r)*r + x%r at
+    // (y/r, x/r).  Both offsets split into a per-channel base (b*Cout + c)*H*W and a per-pixel part.
+    const int Wo = W / r;
+    const int plane = (int)(HW / rr);
+    int in_off[4], out_off[4];
+#pragma unroll
+    for (int nb = 0; nb < 4; ++nb) {
+      const int py = y0 + 2 * wave + (nb >> 1), px = x0 + (nb & 1) * 16 + l16;
+      const int yq = py / r, xq = px / r;
+      in_off[nb] = (py < H && px < W) ? py * W + px : -1;
+      out_off[nb] = ((py - yq * r) * r + (px - xq * r)) * plane + yq * Wo + xq;
+    }
+    steps3<0, MI>([&](auto mi_c) {
+      constexpr int mi = decltype(mi_c)::value;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int cc = cob + mi * 16 + reg;
+        if (cc >= Cout) continue;
+        const float bv = a.bias ? a.bias[cc] : 0.f;
+        const int64_t cbase = ((int64_t)b * Cout + cc) * HW;
+        const float* __restrict__ zp = a.zprev + cbase;
+        float* __restrict__ yo = a.y + cbase;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+          if (in_off[nb] >= 0) yo[out_off[nb]] = (acc[mi][nb][reg] + bv) * zp[in_off[nb]];
+      }
+    });
+    return;
+  }
   steps3<0, MI>([&](auto mi_c) {
     constexpr int mi = decltype(mi_c)::value;
     const int co = cob + mi * 16;  // first of the lane's 4 channels (multiple of 4)
@@ -302,19 +327,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int C = Cout / rr, c = co / rr;
         const int si = (r == 4) ? ((co >> 2) & 3) : 0;
         const int64_t rowbase = (((int64_t)b * C + c) * (H * r) + (int64_t)py * r + si) * ((int64_t)W * r);
+        const bool want_act = (epi == NQ_EPI_PS_GELU);
+        float g0, g1, g2, g3, d0 = v0, d1 = v1, d2 = v2, d3 = v3;  // PS: z = conv; PS_GELU: z = gelu'(conv)
+        if (want_act) {
+          nq_gelu_pair(v0, g0, d0); nq_gelu_pair(v1, g1, d1); nq_gelu_pair(v2, g2, d2); nq_gelu_pair(v3, g3, d3);
+        }
         if (r == 2) {
           const int64_t o0 = rowbase + (int64_t)px * 2, o1 = o0 + (int64_t)W * 2;
-          *reinterpret_cast<float2*>(a.z + o0) = make_float2(v0, v1);
-          *reinterpret_cast<float2*>(a.z + o1) = make_float2(v2, v3);
-          if (epi == NQ_EPI_PS_GELU) {
-            *reinterpret_cast<float2*>(a.y + o0) = make_float2(gelu3(v0), gelu3(v1));
-            *reinterpret_cast<float2*>(a.y + o1) = make_float2(gelu3(v2), gelu3(v3));
+          *reinterpret_cast<float2*>(a.z + o0) = make_float2(d0, d1);
+          *reinterpret_cast<float2*>(a.z + o1) = make_float2(d2, d3);
+          if (want_act) {
+            *reinterpret_cast<float2*>(a.y + o0) = make_float2(g0, g1);
+            *reinterpret_cast<float2*>(a.y + o1) = make_float2(g2, g3);
           }
         } else {
           const int64_t o0 = rowbase + (int64_t)px * 4;
-          *reinterpret_cast<float4*>(a.z + o0) = make_float4(v0, v1, v2, v3);
-          if (epi == NQ_EPI_PS_GELU)
-            *reinterpret_cast<float4*>(a.y + o0) = make_float4(gelu3(v0), gelu3(v1), gelu3(v2), gelu3(v3));
+          *reinterpret_cast<float4*>(a.z + o0) = make_float4(d0, d1, d2, d3);
+          if (want_act) *reinterpret_cast<float4*>(a.y + o0) = make_float4(g0, g1, g2, g3);
         }
         continue;
       }
@@ -326,17 +355,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (epi == NQ_EPI_PS_GELU || epi == NQ_EPI_PS) {
           const int C = Cout / rr, c = cc / rr, rem = cc - c * rr, si = rem / r, sj = rem - si * r;
           const int64_t o = (((int64_t)b * C + c) * (H * r) + (int64_t)py * r + si) * ((int64_t)W * r) + (int64_t)px * r + sj;
-          a.z[o] = v;
-          if (epi == NQ_EPI_PS_GELU) a.y[o] = gelu3(v);
-        } else if (epi == NQ_EPI_DGRAD_GELU) {
-          const int64_t i = ((int64_t)b * Cout + cc) * HW + (int64_t)py * W + px;
-          v *= gelu3_grad(a.zprev[i]);
-          if (r == 1) {
-            a.y[i] = v;
+          if (epi == NQ_EPI_PS_GELU) {
+            float gv, dv;
+            nq_gelu_pair(v, gv, dv);
+            a.y[o] = gv;
+            a.z[o] = dv;
           } else {
-            const int yq = py / r, xq = px / r;
-            const int chn = cc * rr + (py - yq * r) * r + (px - xq * r);
-            a.y[(((int64_t)b * Cout * rr + chn) * (H / r) + yq) * (int64_t)(W / r) + xq] = v;
+            a.z[o] = v;
           }
         } else {
           const int64_t o = ((int64_t)b * Cout + cc) * HW + (int64_t)py * W + px;

@@ -71,12 +71,6 @@ __device__ __forceinline__ void igemm_steps(F&& f) {
 
 __device__ __forceinline__ float gelu_exact(float v) { return v * 0.5f * (1.0f + erff(v * 0.70710678118654752440f)); }
 
-__device__ __forceinline__ float gelu_grad_exact(float v) {
-  float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752440f));
-  float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
-  return cdf + v * pdf;
-}
-
 // Kernel rows per slice: narrow channel tiles (MI <= 4: the data gradients 148->44, 176->53, 848->64) would otherwise
 // run only 6*MI MFMAs between barriers; they take a whole channel group (all KS kernel rows) per slice instead.
 constexpr int khs_for(int mi) { return (mi <= 4) ? KS : 1; }
@@ -292,20 +286,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (px >= W) continue;
         const f32x4 v = acc[mi][ni];
         const float v0 = v[0] + bv.x, v1 = v[1] + bv.y, v2 = v[2] + bv.z, v3 = v[3] + bv.w;
+        float g0, g1, g2, g3, d0 = v0, d1 = v1, d2 = v2, d3 = v3;  // PS: z = conv; PS_GELU: z = gelu'(conv)
+        if (want_act) {
+          nq_gelu_pair(v0, g0, d0); nq_gelu_pair(v1, g1, d1); nq_gelu_pair(v2, g2, d2); nq_gelu_pair(v3, g3, d3);
+        }
         if (r == 2) {
           const int64_t o0 = rowbase + (int64_t)px * 2, o1 = o0 + (int64_t)W * 2;
-          *reinterpret_cast<float2*>(a.z + o0) = make_float2(v0, v1);
-          *reinterpret_cast<float2*>(a.z + o1) = make_float2(v2, v3);
+          *reinterpret_cast<float2*>(a.z + o0) = make_float2(d0, d1);
+          *reinterpret_cast<float2*>(a.z + o1) = make_float2(d2, d3);
           if (want_act) {
-            *reinterpret_cast<float2*>(a.y + o0) = make_float2(gelu_exact(v0), gelu_exact(v1));
-            *reinterpret_cast<float2*>(a.y + o1) = make_float2(gelu_exact(v2), gelu_exact(v3));
+            *reinterpret_cast<float2*>(a.y + o0) = make_float2(g0, g1);
+            *reinterpret_cast<float2*>(a.y + o1) = make_float2(g2, g3);
           }
         } else {
           const int64_t o0 = rowbase + (int64_t)px * 4;
-          *reinterpret_cast<float4*>(a.z + o0) = make_float4(v0, v1, v2, v3);
-          if (want_act)
-            *reinterpret_cast<float4*>(a.y + o0) = make_float4(gelu_exact(v0), gelu_exact(v1), gelu_exact(v2), gelu_exact(v3));
+          *reinterpret_cast<float4*>(a.z + o0) = make_float4(d0, d1, d2, d3);
+          if (want_act) *reinterpret_cast<float4*>(a.y + o0) = make_float4(g0, g1, g2, g3);
         }
+      }
+    });
+    return;
+  }
+  if (epi == NQ_EPI_DGRAD_GELU) {
+    // data gradient w.r.t. the pre-activation below: acc * gelu'(z) (zprev = the derivative saved by the forward
+    // epilogue, same NCHW layout as this conv's output), stored un-shuffled (conv layout of the layer below: channel
+    // c*r*r + (y%r)*r + x%r at (y/r, x/r)); r == 1 keeps the layout.  Per-channel base + per-pixel offsets.
+    const int Wo = W / r, plane = (int)(HW / rr), yq = py / r;
+    int in_off[2], out_off[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int px = x0 + ni * 16 + l16, xq = px / r;
+      in_off[ni] = (px < W) ? py * W + px : -1;
+      out_off[ni] = ((py - yq * r) * r + (px - xq * r)) * plane + yq * Wo + xq;
+    }
+    igemm_steps<0, MI>([&](auto mi_c) {
+      constexpr int mi = decltype(mi_c)::value;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = cob + mi * 16 + reg;
+        if (co >= Cout) continue;
+        const float bv = a.bias ? a.bias[co] : 0.f;
+        const int64_t cbase = ((int64_t)b * Cout + co) * HW;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+          if (in_off[ni] >= 0) a.y[cbase + out_off[ni]] = (acc[mi][ni][reg] + bv) * a.zprev[cbase + in_off[ni]];
       }
     });
     return;
@@ -332,19 +356,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (epi == NQ_EPI_PS_GELU || epi == NQ_EPI_PS) {
           const int C = Cout / rr;
           int64_t o = (((int64_t)b * C + c) * (H * r) + (int64_t)py * r + si) * ((int64_t)W * r) + (int64_t)px * r + sj;
-          a.z[o] = v;
-          if (epi == NQ_EPI_PS_GELU) a.y[o] = gelu_exact(v);
-        } else if (epi == NQ_EPI_DGRAD_GELU) {
-          // data gradient w.r.t. the pre-activation below: acc * gelu'(z), stored un-shuffled (conv layout of the
-          // layer below: channel c*r*r + (y%r)*r + x%r at (y/r, x/r)); r == 1 keeps the layout
-          const int64_t i = ((int64_t)b * Cout + co) * HW + (int64_t)py * W + px;
-          v *= gelu_grad_exact(a.zprev[i]);
-          if (r == 1) {
-            a.y[i] = v;
+          if (epi == NQ_EPI_PS_GELU) {
+            float gv, dv;
+            nq_gelu_pair(v, gv, dv);
+            a.y[o] = gv;
+            a.z[o] = dv;
           } else {
-            const int yq = py / r, xq = px / r;
-            const int ch = co * rr + (py - yq * r) * r + (px - xq * r);
-            a.y[(((int64_t)b * Cout * rr + ch) * (H / r) + yq) * (int64_t)(W / r) + xq] = v;
+            a.z[o] = v;
           }
         } else {
           int64_t o = ((int64_t)b * Cout + co) * HW + (int64_t)py * W + px;
@@ -373,11 +391,17 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(ConvArgs a) {
     const int r = a.r, rr = r * r, C = a.Cout / rr;
     const int c = co / rr, rem = co - c * rr, si = rem / r, sj = rem - si * r;
     int64_t o = (((int64_t)b * C + c) * (a.H * r) + (int64_t)py * r + si) * ((int64_t)a.W * r) + (int64_t)px * r + sj;
-    a.z[o] = v;
-    if (a.epi == NQ_EPI_PS_GELU) a.y[o] = gelu_exact(v);
+    if (a.epi == NQ_EPI_PS_GELU) {
+      float gv, dv;
+      nq_gelu_pair(v, gv, dv);
+      a.y[o] = gv;
+      a.z[o] = dv;
+    } else {
+      a.z[o] = v;
+    }
   } else if (a.epi == NQ_EPI_DGRAD_GELU) {
     const int r = a.r, rr = r * r;
-    v *= gelu_grad_exact(a.zprev[i]);
+    v *= a.zprev[i];
     if (r == 1) {
       a.y[i] = v;
     } else {

@@ -7,15 +7,6 @@ namespace {
 
 constexpr int TPB = 256;
 
-// d/dv gelu(v), exact-erf form (nn.GELU(), models/_layers.py:104-105)
-__device__ __forceinline__ float gelu_grad(float v) {
-  const float kAlpha = 0.70710678118654752440f;        // 1/sqrt(2)
-  const float kBeta = 0.39894228040143267794f;         // 1/sqrt(2*pi)
-  float cdf = 0.5f * (1.0f + erff(v * kAlpha));
-  float pdf = kBeta * expf(-0.5f * v * v);
-  return cdf + v * pdf;
-}
-
 // One workgroup per (b, c, y): reads the r rows Y = y*r+i of da / z (each W*r contiguous floats) and scatters
 // to the r*r planes of dconv.  R = 0 -> runtime r.
 template <int R>
@@ -33,7 +24,7 @@ __global__ __launch_bounds__(TPB) void ps_gelu_bwd_kernel(const float* __restric
   for (int e = threadIdx.x; e < total; e += TPB) {
     int i = e / Wr, X = e - i * Wr;
     int x = X / r, j = X - x * r;
-    float g = da[in_base + e] * gelu_grad(z[in_base + e]);
+    float g = da[in_base + e] * z[in_base + e];  // z = gelu'(pre-activation), saved by the forward epilogue
     dconv[out_base + (int64_t)(i * r + j) * out_plane + x] = g;
   }
 }

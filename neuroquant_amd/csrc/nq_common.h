@@ -14,6 +14,16 @@ static inline int nq_launch_status() {
 
 static inline hipStream_t nq_s(nq_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// exact-erf GELU and its derivative from ONE erf (nn.GELU(), reference models/_layers.py:104-105).  The forward
+// epilogues store the derivative ("dact") next to the activation, so no backward kernel evaluates erf/exp again.
+__device__ __forceinline__ void nq_gelu_pair(float v, float& g, float& dg) {
+  const float e = erff(v * 0.70710678118654752440f);
+  g = v * 0.5f * (1.0f + e);
+  const float cdf = 0.5f * (1.0f + e);
+  const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+  dg = cdf + v * pdf;
+}
+
 // ---- wave / block reductions (wave = 64 lanes) ----
 __device__ __forceinline__ float nq_wave_sum(float v) {
 #pragma unroll

@@ -449,7 +449,7 @@ class DecoderSpec:
     """Static description of a conv decoder stack for `decoder_stack`: per layer (k, shuffle r, gelu after),
     the (fc_h, fc_w) channel->space reshape after layer 0 and whether OutImg is tanh*0.5+0.5."""
 
-    def __init__(self, layers, fc_hw=(1, 1), tanh_out=True, materialize_act=True, precision=None):
+    def __init__(self, layers, fc_hw=(1, 1), tanh_out=True, precision=None):
         self.layers = [tuple(l) for l in layers]
         self.fc_hw = tuple(fc_hw)
         self.tanh_out = tanh_out
@@ -458,10 +458,9 @@ class DecoderSpec:
         self.precision = precision or os.environ.get("NQ_CONV_PRECISION", "bf16x3")
         if self.precision not in ("fp32", "bf16x3"):
             raise ValueError(f"unknown conv precision {self.precision!r}")
-        # True : each block's epilogue writes z AND a = gelu(z); consumers read a (one erf per element).
-        # False: only z is written and every consumer applies GELU while staging its tile (less HBM traffic, but the
-        #        halo / per-tap re-reads repeat the erf 2-6x; measured slower on MI355X, kept for comparison).
-        self.materialize_act = materialize_act
+        # NQ_WGRAD_STREAM=1: weight gradients on a second HIP stream, concurrent with the data-gradient chain (measured
+        # +3 % it/s on HNeRV-3M; off by default so that per-kernel durations in profiles stay separable)
+        self.overlap_wgrad = os.environ.get("NQ_WGRAD_STREAM", "0") == "1"
 
 
 def _space_from_channels(x, fh, fw):
@@ -474,13 +473,22 @@ def _channels_from_space(g, fh, fw):
     return g.view(n, c, hh // fh, fh, ww // fw, fw).permute(0, 1, 3, 5, 2, 4).reshape(n, c * fh * fw, hh // fh, ww // fw)
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    key = torch.device(device).index
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 class _DecoderStackFn(Function):
     """Whole decoder (reference HNeRV.py:49-71 / NeRV.py:44-65) as ONE autograd node with an explicit schedule.
 
-    Only pre-activations are ever written: every conv stores PixelShuffle(conv+bias) (EPI_PS) and the next conv /
-    the weight-gradient kernel apply exact GELU while staging their input tile; the data-gradient kernel multiplies
-    by gelu'(z) and un-shuffles in its epilogue (EPI_DGRAD_GELU).  So per block: 1 launch forward, 2 backward
-    (+ the tiny split-K reductions), no elementwise passes over activations.
+    Every block's conv epilogue writes a = gelu(PixelShuffle(conv+bias)) and d = gelu'(...) from one erf (EPI_PS_GELU);
+    the data-gradient kernel of the layer above multiplies by d and un-shuffles in its epilogue (EPI_DGRAD_GELU).  So
+    per block: 1 launch forward, 2 backward (+ the small split-K reductions), no elementwise passes over activations.
     """
 
     @staticmethod
@@ -488,8 +496,8 @@ class _DecoderStackFn(Function):
         x = _dev(emb, "embedding")
         n = len(spec.layers)
         saved_in, saved_z, metas = [], [], []
-        in_gelu = False      # x currently holds pre-activations that still need GELU (materialize_act=False only)
-        zprev = None         # pre-activation behind x (for gelu' in the data gradient)
+        in_gelu = False      # (kept in the metas for the generic kernels' GELU-on-load option; unused by this schedule)
+        zprev = None         # gelu'(pre-activation) behind x, saved by the producing epilogue
         for l, (k, r, act) in enumerate(spec.layers):
             W = _dev(wb[2 * l], "weight")
             b = _dev(wb[2 * l + 1], "bias") if wb[2 * l + 1] is not None else None
@@ -509,7 +517,7 @@ class _DecoderStackFn(Function):
             if last:
                 epi = EPI_TANH if spec.tanh_out else EPI_PLAIN
             elif act:
-                epi = EPI_PS_GELU if spec.materialize_act else EPI_PS
+                epi = EPI_PS_GELU
             elif r > 1:
                 epi = EPI_PS
             else:
@@ -524,7 +532,7 @@ class _DecoderStackFn(Function):
             if epi == EPI_PS_GELU:
                 x, zprev, in_gelu = y, z, False
             elif epi == EPI_PS:
-                x, zprev, in_gelu = z, z, act
+                x, zprev, in_gelu = z, None, False
             else:
                 x, zprev, in_gelu = y, None, False
             if l == 0 and spec.fc_hw != (1, 1):
@@ -545,17 +553,36 @@ class _DecoderStackFn(Function):
         else:
             dconv = g
         grads = [None] * (2 * n)
-        for l in range(n - 1, -1, -1):
+        # The weight gradients are off the critical path (only the data gradients chain): they run on a second HIP
+        # stream so that their workgroups fill the partial last rounds ("tails") of the data-gradient kernels and the
+        # launch gaps of the small deep layers.  Every dconv stays referenced until the streams are joined.
+        main = torch.cuda.current_stream()
+        side = _side_stream(g.device) if spec.overlap_wgrad else None
+        keep = []
+
+        def wgrad(l, dconv):
             k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
             x_in = xs[l]
             Bx, _, Hx, Wx = x_in.shape
             if spec.precision == "bf16x3" and not in_gelu and conv_wgrad3_supported(Bx, cin, Hx, Wx, cout, k):
-                dw, db = conv_wgrad3_raw(x_in, dconv, cout, k, has_b)
-            elif spec.precision == "bf16x3" and not in_gelu and cout <= 4 and cin > 4 and cout * k * k <= 64 \
+                return conv_wgrad3_raw(x_in, dconv, cout, k, has_b)
+            if spec.precision == "bf16x3" and not in_gelu and cout <= 4 and cin > 4 and cout * k * k <= 64 \
                     and conv_wgrad3_supported(Bx, cout, Hx, Wx, cin, k):
-                dw, db = conv_wgrad_swapped3(x_in, dconv, cout, k, has_b)
+                return conv_wgrad_swapped3(x_in, dconv, cout, k, has_b)
+            return conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu)
+
+        for l in range(n - 1, -1, -1):
+            k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
+            if side is not None:
+                keep.append(dconv)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    dw, db = wgrad(l, dconv)
+                for t in (dw, db):
+                    if t is not None:
+                        t.record_stream(main)
             else:
-                dw, db = conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu)
+                dw, db = wgrad(l, dconv)
             grads[2 * l], grads[2 * l + 1] = dw, db
             if l == 0:
                 break
@@ -571,6 +598,9 @@ class _DecoderStackFn(Function):
             if not actp:
                 if l == 1 and spec.fc_hw != (1, 1):
                     dconv = _channels_from_space(dconv, *spec.fc_hw).contiguous()
+        if side is not None:
+            main.wait_stream(side)
+            keep.clear()
         return (None, None) + tuple(grads)
 
 

@@ -218,10 +218,10 @@ def test_conv_bf16x3(ops, case):
     if epi == "dgrad":
         # treat w as the stored conv (Cout_w=Cin here, Cin_w=Cout): gradient conv maps Cin -> Cout channels
         wst = torch.randn(Cin, Cout, k, k, generator=g) / math.sqrt(Cin * k * k)
-        zprev = torch.randn(B, Cout, H, W, generator=g)
+        pre = torch.randn(B, Cout, H, W, generator=g).double().requires_grad_(True)
+        zprev = torch.autograd.grad(F.gelu(pre).sum(), pre)[0].float()   # the saved gelu'(pre-activation)
         ref = torch.nn.grad.conv2d_input((B, Cout, H, W), wst.double(), xd, padding=k // 2)
-        zp = zprev.double().requires_grad_(True)
-        ref = F.pixel_unshuffle(ref * torch.autograd.grad(F.gelu(zp).sum(), zp)[0], r)
+        ref = F.pixel_unshuffle(ref * zprev.double(), r)
         y, _ = ops.conv3_forward_raw(x.to(DEV), ops.weight_layout3(wst.to(DEV), transposed=True), None, Cout, k,
                                      ops.EPI_DGRAD_GELU, r, zprev=zprev.to(DEV))
     else:
@@ -229,9 +229,10 @@ def test_conv_bf16x3(ops, case):
         code = {"plain": ops.EPI_PLAIN, "psgelu": ops.EPI_PS_GELU, "tanh": ops.EPI_TANH}[epi]
         y, z = ops.conv3_forward_raw(x.to(DEV), ops.weight_layout3(w.to(DEV)), b.to(DEV), Cout, k, code, r)
         if epi == "psgelu":
-            ref = F.pixel_shuffle(ref, r)
-            close(z, ref, rtol=2e-5, atol=3e-5)
-            ref = F.gelu(ref)
+            ref = F.pixel_shuffle(ref, r).requires_grad_(True)
+            act = F.gelu(ref)
+            close(z, torch.autograd.grad(act.sum(), ref)[0], rtol=2e-5, atol=3e-5)   # z = gelu'(conv), saved for backward
+            ref = act.detach()
         elif epi == "tanh":
             ref = torch.tanh(ref) * 0.5 + 0.5
     close(y, ref, rtol=2e-5, atol=3e-5)
@@ -394,10 +395,11 @@ def test_decode_vs_reference(ops, golden, arch):
 
 
 @pytest.mark.parametrize("prec", ("fp32", "bf16x3"))
-@pytest.mark.parametrize("mat", (True, False))
+@pytest.mark.parametrize("wstream", (False, True))
 @pytest.mark.parametrize("arch", ("hnerv", "nerv"))
-def test_fused_decoder_stack_matches_per_layer_path(ops, golden, arch, mat, prec):
-    """ops.decoder_stack (pre-activations only, GELU applied by the consumers) vs the per-layer fused kernels vs CPU."""
+def test_fused_decoder_stack_matches_per_layer_path(ops, golden, arch, wstream, prec):
+    """ops.decoder_stack (whole decoder as one autograd node; weight gradients in line or on the second stream) vs the
+    CPU autograd of the oracle's decoder, and the module path routes through the same node."""
     from neuroquant_amd.quantization import QuantModel
     from neuroquant_amd.models import _decode
     z = golden("decode.npz")
@@ -405,7 +407,7 @@ def test_fused_decoder_stack_matches_per_layer_path(ops, golden, arch, mat, prec
     qnn = QuantModel(_build(arch, sd), hadamard=False, weight_quant_params=dict(n_bits=8, channel_wise=True))
     emb = G(z[f"{arch}_emb"])
     spec, provs = _decode._fused_stack(qnn.model)
-    spec.materialize_act = mat
+    spec.overlap_wgrad = wstream
     spec.precision = prec
     g = torch.Generator().manual_seed(4)
     ws = [tuple(t.detach().clone().requires_grad_(True) for t in p()) for p in provs]
@@ -423,7 +425,7 @@ def test_fused_decoder_stack_matches_per_layer_path(ops, golden, arch, mat, prec
         close(Wg.grad, Wc.grad, rtol=2e-3, atol=2e-4 * sw)
         close(bg.grad, bc.grad, rtol=2e-3, atol=2e-4 * float(bc.grad.abs().max()))
     # and the module path under autograd routes through the same node
-    if mat and prec == ops.DecoderSpec([]).precision:
+    if not wstream and prec == ops.DecoderSpec([]).precision:
         img, elist, _ = qnn(emb)
         assert len(elist) == 1 and torch.equal(img, out.detach()) is True
 
