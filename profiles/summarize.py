@@ -63,6 +63,7 @@ def main():
             row.update(mfma_busy_frac=round(s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / cyc, 3),
                        wait_any=round(s.get("SQ_WAIT_ANY", 0) / wc, 3), wait_inst=round(s.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
                        active=round(s.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3),
+                       valu_active=round(s.get("SQ_ACTIVE_INST_VALU", 0) / wc, 3),
                        lds_bank_conflict_cycles=int(s.get("SQ_LDS_BANK_CONFLICT", 0)))
         table.append(row)
     table.sort(key=lambda r: -r["dur_us"] * r["launches"])
