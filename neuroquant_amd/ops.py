@@ -441,6 +441,110 @@ class _ConvFn(Function):
         return dx, dw, db, None, None
 
 
+# ---- twice-differentiable convolution (Hessian-vector products of the Omega bit-allocation criterion) ----
+# A stride-1 'same' convolution is bilinear in (x, w), so F = conv(x, w), D = dgrad(gy, w) and Wg = wgrad(x, gy) are
+# closed under differentiation:  dF = (D(gy,w), Wg(x,gy));  dD = (F(g,w), Wg(g,gy));  dWg = (D(gy,G), F(x,G)).
+# Each is an autograd Function whose backward is built from the other two, so create_graph=True works to any order
+# on the same HIP kernels as the calibration loop (bf16x3 where the grid fills the chip, exact fp32 MFMA otherwise).
+def _use3(precision):
+    return (precision or os.environ.get("NQ_CONV_PRECISION", "bf16x3")) == "bf16x3"
+
+
+def _conv_plain(x, w, precision=None):
+    cout, cin, k, _ = w.shape
+    B, _, H, W = x.shape
+    if _use3(precision) and conv3_supported(B, cin, H, W, cout, k):
+        return conv3_forward_raw(x, weight_layout3(w), None, cout, k, EPI_PLAIN, 1)[0]
+    wt, dims, _, _ = weight_layouts(w, need_bwd=False)
+    return conv_forward_raw(x, wt, dims, None, cout, k, EPI_PLAIN, 1)[0]
+
+
+def _dgrad_plain(gy, w, precision=None):
+    cout, cin, k, _ = w.shape
+    B, _, H, W = gy.shape
+    if _use3(precision) and conv3_supported(B, cout, H, W, cin, k):
+        return conv3_forward_raw(gy, weight_layout3(w, transposed=True), None, cin, k, EPI_PLAIN, 1)[0]
+    _, _, wb, dims_b = weight_layouts(w, need_bwd=True)
+    return conv_forward_raw(gy, wb, dims_b, None, cin, k, EPI_PLAIN, 1)[0]
+
+
+def _wgrad_plain(x, gy, k, precision=None):
+    B, cin, H, W = x.shape
+    cout = gy.shape[1]
+    if _use3(precision) and conv_wgrad3_supported(B, cin, H, W, cout, k):
+        return conv_wgrad3_raw(x, gy, cout, k, False)[0]
+    if _use3(precision) and cout <= 4 and cin > 4 and cout * k * k <= 64 and conv_wgrad3_supported(B, cout, H, W, cin, k):
+        return conv_wgrad_swapped3(x, gy, cout, k, False)[0]
+    return conv_wgrad_raw(x, gy, cout, k, False)[0]
+
+
+class _ConvF(Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        x, w = _dev(x, "x").contiguous(), _dev(w, "weight").contiguous()
+        ctx.save_for_backward(x, w)
+        return _conv_plain(x, w)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gy = gy.contiguous()
+        return (_ConvD.apply(gy, w) if ctx.needs_input_grad[0] else None,
+                _ConvWg.apply(x, gy, w.shape[-1]) if ctx.needs_input_grad[1] else None)
+
+
+class _ConvD(Function):
+    @staticmethod
+    def forward(ctx, gy, w):
+        gy, w = _dev(gy, "gy").contiguous(), _dev(w, "weight").contiguous()
+        ctx.save_for_backward(gy, w)
+        return _dgrad_plain(gy, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        gy, w = ctx.saved_tensors
+        g = g.contiguous()
+        return (_ConvF.apply(g, w) if ctx.needs_input_grad[0] else None,
+                _ConvWg.apply(g, gy, w.shape[-1]) if ctx.needs_input_grad[1] else None)
+
+
+class _ConvWg(Function):
+    @staticmethod
+    def forward(ctx, x, gy, k):
+        x, gy = _dev(x, "x").contiguous(), _dev(gy, "gy").contiguous()
+        ctx.save_for_backward(x, gy)
+        return _wgrad_plain(x, gy, k)
+
+    @staticmethod
+    def backward(ctx, G):
+        x, gy = ctx.saved_tensors
+        G = G.contiguous()
+        return (_ConvD.apply(gy, G) if ctx.needs_input_grad[0] else None,
+                _ConvF.apply(x, G) if ctx.needs_input_grad[1] else None, None)
+
+
+def conv2d_dd(x, w, b=None):
+    """stride-1 'same' convolution (+bias), differentiable to any order (reference F.conv2d, quant_layer.py:80, as used
+    under torch.autograd.grad(create_graph=True) by methods/bit_assign.py:88-114)."""
+    y = _ConvF.apply(x, w)
+    return y if b is None else y + b.view(1, -1, 1, 1)
+
+
+def decoder_stack_dd(emb, spec, weights):
+    """Decoder forward (reference HNeRV.py:49-71 / NeRV.py:44-65) on the twice-differentiable convolution; PixelShuffle /
+    exact GELU / tanh go through PyTorch's own differentiable elementwise ops (not on the calibration hot path)."""
+    x = emb
+    for l, ((k, r, act), (W, b)) in enumerate(zip(spec.layers, weights)):
+        x = conv2d_dd(x, W, b)
+        if l == 0 and spec.fc_hw != (1, 1):
+            x = _space_from_channels(x, *spec.fc_hw)
+        if r > 1:
+            x = torch.nn.functional.pixel_shuffle(x, r)
+        if act:
+            x = torch.nn.functional.gelu(x)
+    return torch.tanh(x) * 0.5 + 0.5 if spec.tanh_out else x
+
+
 def conv2d_fused(x, w, b, epilogue=EPI_PLAIN, r=1):
     return _ConvFn.apply(x, w, b, epilogue, r)
 

@@ -357,3 +357,50 @@ def calibrate(qs: QuantStack, cali_data: torch.Tensor, frames: torch.Tensor, ord
         for t in (L.wa, L.ba, L.wd, L.bd):
             t.requires_grad_(False)
     return log
+
+
+# ----------------------------------------------------------------------------------------------
+# Sensitivity criteria of the bit-allocation sweep (methods/bit_assign.py:57-118, 120-168, 171-217)
+# ----------------------------------------------------------------------------------------------
+def weight_perturbation(qs: QuantStack):
+    """quant_layer.py:86-89 / quant_model.py:82-87: org_weight - weight_quantizer(weight), one tensor per layer.  The
+    quantiser sees the raw (un-transformed) weight there, also when Hadamard is on."""
+    out = []
+    for L in qs.dec.layers:
+        nl = 2 ** L.n_bits
+        if qs.phase == "uaq":
+            Wq = uaq_fake_quant(L.w, L.wd, L.wz, nl)
+        else:
+            Wq, _ = adaround_fake_quant(L.w, L.wa, L.wd, L.wz, nl, L.w_soft)
+        out.append((L.w - Wq).detach())
+    return out
+
+
+def sensitivity(dec: Decoder, vec: Sequence[torch.Tensor], batches, mode: str, max_batches: int = 10):
+    """mode 'omega': sum_l <v_l, (H v)_l>, H = Hessian of nn.MSELoss (mean over ALL elements) w.r.t. the decoder conv
+    weights, accumulated (summed) over the first `max_batches` batches (bit_assign.py:57-118, 171-199).
+    mode 'fisher_diag': sum_l <v_l^2, g_l^2>, g = dL/dW accumulated over the same batches (120-168, 200-211).
+    batches: iterable of (emb, img).  Returns (total, per-layer list, per-layer accumulated gradient tensors)."""
+    ws = [L.w.clone().requires_grad_(True) for L in dec.layers]
+    bs = [L.b.clone().requires_grad_(True) for L in dec.layers]
+    acc = [torch.zeros_like(w) for w in ws]
+    for i, (emb, img) in enumerate(batches):
+        if i >= max_batches:
+            break
+        out = dec.forward(emb, list(zip(ws, bs)))
+        loss = F.mse_loss(out, img)
+        if mode == "omega":
+            grad_f = torch.autograd.grad(loss, ws, create_graph=True)
+            prod = sum((g * v).sum() for g, v in zip(grad_f, vec))
+            hv = torch.autograd.grad(prod, ws)
+        elif mode == "fisher_diag":
+            hv = torch.autograd.grad(loss, ws)
+        else:
+            raise ValueError('Not implemented sensitivity criteria: {}'.format(mode))
+        for a, h in zip(acc, hv):
+            a += h
+    if mode == "omega":
+        per = [(g * v).sum() for g, v in zip(acc, vec)]
+    else:
+        per = [(v.pow(2) * g.pow(2)).sum() for g, v in zip(acc, vec)]
+    return sum(per), per, acc

@@ -21,6 +21,9 @@ Fixtures (what each one pins; reference file:line):
   traj_hnerv.npz     tiny HNeRV: checkpoint, embeddings, batch order, per-iteration losses of the
                      real model_reconstruction, final alpha/delta/x_quant, PSNRs    calib_model.py:92-240
   traj_nerv_had.npz  tiny NeRV + Hadamard: same (FWHT via stub -> "parity unpinned" at the transform)
+  omega.npz          tiny HNeRV (checkpoint of traj_hnerv.npz): get_perturbation() and the reference's own
+                     sensitivity_criterion ('omega' = v'Hv by double backward, 'fisher_diag') for the two toy
+                     candidates of bit_assign.py:27-30                          bit_assign.py:57-217
 """
 import argparse
 import json
@@ -495,6 +498,55 @@ def gen_traj(name, arch, cls, cfg, hadamard, iters, train_epochs, lr_train, seed
     save(name, **out)
 
 
+def gen_omega():
+    """Runs methods/bit_assign.py:sensitivity_criterion itself.  The only accommodation: run_hessian_vector_product
+    calls `.cuda()` unconditionally (bit_assign.py:110) and this container has no GPU, so Tensor.cuda is an identity
+    for the duration of the call (arithmetic untouched, everything stays fp32 on the CPU)."""
+    import copy
+    import methods.bit_assign as ref_ba
+    z = np.load(os.path.join(HERE, "traj_hnerv.npz"))
+    model = HNeRV(TINY_HNERV)
+    model.load_state_dict({k[3:].replace("/", "."): torch.from_numpy(z[k]) for k in z.files if k.startswith("sd:")}, strict=True)
+    model.eval()
+    frames = load_frames()
+    n, B = frames.shape[0], 2
+    batches = [dict(img=frames[i:i + B], idx=torch.arange(i, i + B), norm_idx=torch.arange(i, i + B).float() / n)
+               for i in range(0, n, B)]
+    with torch.no_grad():
+        emb = torch.cat([model.encode(frames[i:i + 1]) for i in range(n)], 0)
+    out = {"bits": np.array(list(ref_ba.hnerv_candidate.values()))}
+    orig_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for ci, (cand, bits) in enumerate(ref_ba.hnerv_candidate.items()):
+            for mode in ("omega", "fisher_diag"):
+                # same sequence as bit_assign.py:343-359
+                qnn = QuantModel(model=copy.deepcopy(model), hadamard=False,
+                                 weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
+                qnn.eval()
+                out[f"avgbits{ci}"] = np.array(qnn.set_bitwidth(bits), dtype=np.float64)
+                qnn.set_quant_state(True)
+                with torch.no_grad():
+                    qnn(emb[:B])
+                net = copy.deepcopy(model)
+                score = ref_ba.sensitivity_criterion(mode, "hnerv", net, qnn, batches, use_cuda=False)
+                vec = qnn.get_perturbation()
+                acc = ref_ba.gradtensor_to_vec(net)
+                out[f"{mode}{ci}"] = np.array(float(score), dtype=np.float64)
+                if mode == "omega":
+                    out[f"{mode}{ci}_layers"] = np.array([float((g * v).sum()) for g, v in zip(acc, vec)])
+                else:
+                    out[f"{mode}{ci}_layers"] = np.array([float((v.pow(2) * g.pow(2)).sum()) for g, v in zip(acc, vec)])
+                print(f"  {cand} {bits} {mode}: {float(score):.6e}")
+                if ci == 1:
+                    for li, (g, v) in enumerate(zip(acc, vec)):
+                        out[f"{mode}_acc{li}"] = npy(g)
+                        out[f"vec{li}"] = npy(v)
+    finally:
+        torch.Tensor.cuda = orig_cuda
+    save("omega.npz", **out)
+
+
 GENS = {
     "uaq": gen_uaq,
     "adaround": gen_adaround,
@@ -505,6 +557,7 @@ GENS = {
     "frames": gen_frames,
     "traj_hnerv": lambda: gen_traj("traj_hnerv.npz", "hnerv", HNeRV, TINY_HNERV, False, 400, 150, 2e-3, 903),
     "traj_nerv_had": lambda: gen_traj("traj_nerv_had.npz", "nerv", NeRV, TINY_NERV, True, 200, 150, 2e-3, 904),
+    "omega": gen_omega,
 }
 
 if __name__ == "__main__":

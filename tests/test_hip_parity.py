@@ -635,3 +635,72 @@ def test_fp32_trainer_step_matches_torch(golden):
     for (n, pg), (_, pc) in zip(mg.named_parameters(), mc.named_parameters()):
         if n.startswith("decoder") or n.startswith("head"):
             close(pg.grad, pc.grad, rtol=5e-3, atol=2e-4 * float(pc.grad.abs().max()) + 1e-9)
+
+
+# ------------------------------------------------------------------------------------------ Omega bit allocation
+@pytest.mark.parametrize("case", [(2, 5, 9, 14, 8, 3), (1, 12, 6, 10, 20, 5), (2, 6, 4, 4, 10, 1), (1, 37, 16, 40, 3, 3),
+                                  (2, 44, 24, 96, 148, 5)])
+def test_conv2d_dd_second_order(ops, case):
+    """The twice-differentiable convolution (F / dgrad / wgrad closed under differentiation) vs float64 autograd:
+    value, first-order gradients, and a Hessian-vector product through conv -> gelu -> mean-square."""
+    B, Cin, H, W, Cout, k = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+    b = torch.randn(Cout, generator=g) * 0.1
+    v = torch.randn(w.shape, generator=g) * 0.05
+    u = torch.randn(x.shape, generator=g) * 0.05
+
+    def run(conv, x, w, b, v, u):
+        x, w, b = (t.clone().requires_grad_(True) for t in (x, w, b))
+        y = conv(x, w, b)
+        loss = F.gelu(y).pow(2).mean()
+        gx, gw = torch.autograd.grad(loss, (x, w), create_graph=True)
+        prod = (gw * v).sum() + (gx * u).sum()
+        hx, hw, hb = torch.autograd.grad(prod, (x, w, b))
+        return y, gx, gw, hx, hw, hb
+
+    ref = run(lambda x, w, b: F.conv2d(x, w, b, padding=k // 2), *(t.double() for t in (x, w, b, v, u)))
+    got = run(ops.conv2d_dd, *(t.to(DEV) for t in (x, w, b, v, u)))
+    for name, a, r in zip(("y", "gx", "gw", "hx", "hw", "hb"), got, ref):
+        s = float(r.detach().abs().max()) + 1e-30
+        close(a, r, rtol=2e-3, atol=3e-5 * s)
+
+
+@pytest.mark.parametrize("mode", ("omega", "fisher_diag"))
+def test_sensitivity_criterion_matches_reference(ops, golden, mode):
+    """methods.bit_assign.sensitivity_criterion on the GPU vs the values the reference's own function produced for the
+    tiny HNeRV checkpoint (tests/golden/omega.npz), same batches in the same order; per layer and in total."""
+    from neuroquant_amd.methods import bit_assign
+    from neuroquant_amd.quantization import QuantModel
+    import copy
+    zt, zo = golden("traj_hnerv.npz"), golden("omega.npz")
+    sd = state_dict_from_npz(zt, "sd:")
+    frames = G(golden("frames_320x640.npz")["frames"]).float() / 255.0
+    n = frames.shape[0]
+    batches = [dict(img=frames[i:i + 2], idx=torch.arange(i, i + 2, device=DEV),
+                    norm_idx=torch.arange(i, i + 2, device=DEV).float() / n) for i in range(0, n, 2)]
+    emb = G(zt["emb"])
+    scores = []
+    for ci in (0, 1):
+        bits = [int(b) for b in zo["bits"][ci]]
+        model = _build("hnerv", sd)
+        qnn = QuantModel(copy.deepcopy(model), hadamard=False, weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
+        qnn.eval()
+        assert float(qnn.set_bitwidth(bits)) == float(zo[f"avgbits{ci}"])
+        qnn.set_quant_state(True)
+        with torch.no_grad():
+            qnn(emb[:2])
+        if ci == 1:
+            for li, v in enumerate(qnn.get_perturbation()):
+                close(v, zo[f"vec{li}"])                                    # perturbations bit-exact
+        net = copy.deepcopy(model)
+        score = float(bit_assign.sensitivity_criterion(mode, "hnerv", net, qnn, batches))
+        ref = float(zo[f"{mode}{ci}"])
+        acc = bit_assign.gradtensor_to_vec(net)
+        vec = [v.detach() for v in qnn.get_perturbation()]
+        per = [float((g * v).sum()) if mode == "omega" else float((v.pow(2) * g.pow(2)).sum()) for g, v in zip(acc, vec)]
+        close(np.array(per), zo[f"{mode}{ci}_layers"], rtol=5e-3, atol=2e-4 * abs(ref))
+        assert abs(score - ref) <= 2e-3 * abs(ref), (score, ref)
+        scores.append(score)
+    assert (scores[0] < scores[1]) == (float(zo[f"{mode}0"]) < float(zo[f"{mode}1"]))   # same candidate wins

@@ -223,3 +223,46 @@ def test_trajectory_nerv_hadamard(golden):
     with torch.no_grad():
         p = O.psnr_per_frame(qs.forward(emb), frames)
     assert abs(float(p.mean()) - float(z["psnr_q_opt"].mean())) < 0.02
+
+
+# ------------------------------------------------------------------------------------------ Omega bit allocation
+def _omega_setup(golden):
+    zt, zo = golden("traj_hnerv.npz"), golden("omega.npz")
+    sd = state_dict_from_npz(zt, "sd:")
+    frames = T(golden("frames_320x640.npz")["frames"]).float() / 255.0
+    emb = T(zt["emb"])
+    batches = [(emb[i:i + 2], frames[i:i + 2]) for i in range(0, frames.shape[0], 2)]
+    return zo, sd, batches
+
+
+@pytest.mark.parametrize("ci", (0, 1))
+def test_sensitivity_criteria_match_reference(golden, ci):
+    """oracle sensitivity() vs the reference's own sensitivity_criterion (bit_assign.py:171-217) on the tiny HNeRV
+    checkpoint: perturbations bit-exact, Omega = v'Hv and the diagonal-Fisher score to fp32 summation noise."""
+    zo, sd, batches = _omega_setup(golden)
+    bits = [int(b) for b in zo["bits"][ci]]
+    dec = O.Decoder.from_state_dict(sd, "hnerv", [5, 4, 4, 2, 2])
+    qs = O.QuantStack(dec, bits, False)
+    assert qs.avg_bits() == float(zo[f"avgbits{ci}"])
+    vec = O.weight_perturbation(qs)
+    if ci == 1:
+        for li, v in enumerate(vec):
+            eq(v, zo[f"vec{li}"])
+    for mode in ("omega", "fisher_diag"):
+        total, per, acc = O.sensitivity(dec, vec, batches, mode)
+        eq(np.array([float(p) for p in per]), zo[f"{mode}{ci}_layers"], rtol=2e-4, atol=1e-7 * abs(float(zo[f"{mode}{ci}"])))
+        assert abs(float(total) - float(zo[f"{mode}{ci}"])) <= 2e-4 * abs(float(zo[f"{mode}{ci}"]))
+        if ci == 1:
+            for li, g in enumerate(acc):
+                ref = zo[f"{mode}_acc{li}"]
+                eq(g, ref, rtol=1e-3, atol=2e-5 * float(np.abs(ref).max()))
+
+
+def test_omega_ranks_candidates_like_reference(golden):
+    zo, sd, batches = _omega_setup(golden)
+    scores = []
+    for ci in (0, 1):
+        dec = O.Decoder.from_state_dict(sd, "hnerv", [5, 4, 4, 2, 2])
+        qs = O.QuantStack(dec, [int(b) for b in zo["bits"][ci]], False)
+        scores.append(float(O.sensitivity(dec, O.weight_perturbation(qs), batches, "omega")[0]))
+    assert (scores[0] < scores[1]) == (float(zo["omega0"]) < float(zo["omega1"]))
