@@ -87,6 +87,33 @@ int nq_round_loss_backward(const float* alpha, int64_t n, float b, float weight,
 int nq_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float beta1, float beta2,
                  float eps, float bc2_sqrt, nq_stream_t stream);
 
+/* ---- multi-tensor variants: ONE launch for all layers (the per-iteration parameter side is 14 small tensors; 42
+ * launch-bound kernels become 3).  `segs` is a HOST array (copied into the kernel arguments, <= 16 segments per launch,
+ * longer lists are chunked); every pointer inside is a device pointer.  Per-element arithmetic is identical to the
+ * single-tensor entry points above (same results bit for bit). */
+typedef struct nq_ada_seg {
+  const float* x;      /* weights (rows x row_len) */
+  const float* gy;     /* backward only: gradient w.r.t. the fake-quantised output */
+  const float* alpha;
+  const float* delta;  /* (rows) when per_row, else (1) */
+  const float* zp;
+  float* out;          /* forward: fake-quantised weights; backward: d(alpha) (+ regulariser gradient) */
+  int64_t rows, row_len;
+  int per_row, n_levels, soft; /* soft = soft_targets (forward only) */
+  float reg_weight;    /* backward only: regulariser weight lambda, 0 = none (bias quantisers, warm-up) */
+} nq_ada_seg;
+typedef struct nq_adam_seg {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+} nq_adam_seg;
+int nq_adaround_forward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream);
+int nq_adaround_backward_multi(const nq_ada_seg* segs, int nseg, float reg_b, nq_stream_t stream);
+int nq_adam_step_multi(const nq_adam_seg* segs, int nseg, float step_size, float beta1, float beta2, float eps,
+                       float bc2_sqrt, nq_stream_t stream);
+
 /* Orthonormal Walsh-Hadamard transform along the middle axis (hadamard_along_channel_weight,
  * quant_layer.py:16-22, with the zero-padding of :45-49 and the slice of :71 folded in):
  * x is [outer][n_in][inner] (read as zero for index >= n_in), y is [outer][n_out][inner], transform

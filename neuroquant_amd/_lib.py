@@ -2,7 +2,7 @@
 missing the import of any op raises, loudly."""
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER
+from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER, Structure
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnqhip.so")
@@ -13,6 +13,18 @@ EPI_PLAIN, EPI_PS_GELU, EPI_TANH, EPI_PS, EPI_DGRAD_GELU = 0, 1, 2, 3, 4
 
 class NQLibraryError(RuntimeError):
     pass
+
+
+class AdaSeg(Structure):
+    """nq_ada_seg (include/nq_hip.h): one tensor of a multi-tensor AdaRound launch."""
+    _fields_ = [("x", c_void_p), ("gy", c_void_p), ("alpha", c_void_p), ("delta", c_void_p), ("zp", c_void_p),
+                ("out", c_void_p), ("rows", c_int64), ("row_len", c_int64), ("per_row", c_int), ("n_levels", c_int),
+                ("soft", c_int), ("reg_weight", c_float)]
+
+
+class AdamSeg(Structure):
+    """nq_adam_seg (include/nq_hip.h)."""
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64)]
 
 
 def _load():
@@ -36,6 +48,9 @@ def _load():
     sig("nq_adaround_init", I, P, P, P, P, P, P, L, L, I, P)
     sig("nq_adaround_forward", I, P, P, P, P, P, P, L, L, I, I, I, P)
     sig("nq_adaround_backward", I, P, P, P, P, P, P, L, L, I, I, F, F, P)
+    sig("nq_adaround_forward_multi", I, POINTER(AdaSeg), I, P)
+    sig("nq_adaround_backward_multi", I, POINTER(AdaSeg), I, F, P)
+    sig("nq_adam_step_multi", I, POINTER(AdamSeg), I, F, F, F, F, F, P)
     sig("nq_reduce_ws_floats", L, L)
     sig("nq_round_loss", I, P, L, F, F, P, P, I, P)
     sig("nq_round_loss_backward", I, P, L, F, F, P, P, I, P)
@@ -67,7 +82,7 @@ def _load():
 EXPORTS = (
     "nq_abi_version", "nq_error_string", "nq_scale_init_max", "nq_uaq_forward", "nq_uaq_backward",
     "nq_adaround_init", "nq_adaround_forward", "nq_adaround_backward", "nq_reduce_ws_floats", "nq_round_loss", "nq_round_loss_backward",
-    "nq_adam_step", "nq_fwht", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
+    "nq_adam_step", "nq_adaround_forward_multi", "nq_adaround_backward_multi", "nq_adam_step_multi", "nq_fwht", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
     "nq_conv3_supported", "nq_conv3_weight_bytes", "nq_weight_layout3", "nq_conv_forward3_ws_floats", "nq_conv_forward3",
     "nq_conv_wgrad3_supported", "nq_conv_wgrad3_ws_floats", "nq_conv_wgrad3",
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",

@@ -118,6 +118,33 @@ __global__ __launch_bounds__(TPB) void adaround_alpha_init_kernel(const float* _
 
 __device__ __forceinline__ float soft_target_lin(float a) { return nq_sigmoid(a) * (NQ_ZETA - NQ_GAMMA) + NQ_GAMMA; }
 
+// per-element arithmetic shared by the single-tensor and the multi-tensor kernels (identical op sequence)
+__device__ __forceinline__ float ada_fwd_elem(float xv, float a, float d, float z, float qmax, int soft, float& xq) {
+  float h = soft ? fminf(fmaxf(soft_target_lin(a), 0.f), 1.f) : (a >= 0.f ? 1.f : 0.f);
+  float xi = (floorf(xv / d) + h) + z;
+  xq = fminf(fmaxf(xi, 0.f), qmax);
+  return (xq - z) * d;
+}
+__device__ __forceinline__ float ada_bwd_elem(float xv, float gyv, float a, float d, float z, float qmax, float reg_weight,
+                                              float reg_b) {
+    float s = nq_sigmoid(a);
+  float lin = s * (NQ_ZETA - NQ_GAMMA) + NQ_GAMMA;
+  float h = fminf(fmaxf(lin, 0.f), 1.f);
+  float hp = (lin >= 0.f && lin <= 1.f) ? (NQ_ZETA - NQ_GAMMA) * (s * (1.f - s)) : 0.f;
+  float xi = (floorf(xv / d) + h) + z;
+  float inside = (xi >= 0.f && xi <= qmax) ? 1.f : 0.f;
+  float g = gyv * d * inside * hp;
+  if (reg_weight != 0.f) {
+    // R = w * sum(1 - (2|h-.5|)^b);  dR/dh = -w * b * (2|h-.5|)^(b-1) * 2 * sign(h-.5)
+    float c = h - 0.5f;
+    float t = fabsf(c) * 2.f;
+    float sg = (c > 0.f) ? 1.f : ((c < 0.f) ? -1.f : 0.f);
+    float dRdh = -reg_weight * (reg_b * powf(t, reg_b - 1.f)) * 2.f * sg;
+    g += dRdh * hp;
+  }
+  return g;
+}
+
 __global__ __launch_bounds__(TPB) void adaround_fwd_kernel(const float* __restrict__ x, const float* __restrict__ alpha,
                                                            const float* __restrict__ delta,
                                                            const float* __restrict__ zp, float* __restrict__ y,
@@ -131,11 +158,8 @@ __global__ __launch_bounds__(TPB) void adaround_fwd_kernel(const float* __restri
 #pragma unroll
   for (int e = 0; e < EPT; ++e, i += TPB) {
     if (i < row_len) {
-      float a = alpha[base + i];
-      float h = soft ? fminf(fmaxf(soft_target_lin(a), 0.f), 1.f) : (a >= 0.f ? 1.f : 0.f);
-      float xi = (floorf(x[base + i] / d) + h) + z;
-      float xq = fminf(fmaxf(xi, 0.f), qmax);
-      y[base + i] = (xq - z) * d;
+      float xq;
+      y[base + i] = ada_fwd_elem(x[base + i], alpha[base + i], d, z, qmax, soft, xq);
       if (xq_out) xq_out[base + i] = xq;
     }
   }
@@ -155,22 +179,7 @@ __global__ __launch_bounds__(TPB) void adaround_bwd_kernel(const float* __restri
 #pragma unroll
   for (int e = 0; e < EPT; ++e, i += TPB) {
     if (i < row_len) {
-      float a = alpha[base + i];
-      float s = nq_sigmoid(a);
-      float lin = s * (NQ_ZETA - NQ_GAMMA) + NQ_GAMMA;
-      float h = fminf(fmaxf(lin, 0.f), 1.f);
-      float hp = (lin >= 0.f && lin <= 1.f) ? (NQ_ZETA - NQ_GAMMA) * (s * (1.f - s)) : 0.f;
-      float xi = (floorf(x[base + i] / d) + h) + z;
-      float inside = (xi >= 0.f && xi <= qmax) ? 1.f : 0.f;
-      float g = gy[base + i] * d * inside * hp;
-      if (reg_weight != 0.f) {
-        // R = w * sum(1 - (2|h-.5|)^b);  dR/dh = -w * b * (2|h-.5|)^(b-1) * 2 * sign(h-.5)
-        float c = h - 0.5f;
-        float t = fabsf(c) * 2.f;
-        float sg = (c > 0.f) ? 1.f : ((c < 0.f) ? -1.f : 0.f);
-        float dRdh = -reg_weight * (reg_b * powf(t, reg_b - 1.f)) * 2.f * sg;
-        g += dRdh * hp;
-      }
+      float g = ada_bwd_elem(x[base + i], gy[base + i], alpha[base + i], d, z, qmax, reg_weight, reg_b);
       dalpha[base + i] = g;
     }
   }
@@ -215,12 +224,9 @@ __global__ __launch_bounds__(TPB) void round_loss_bwd_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------
 // Adam (torch/optim/adam.py _single_tensor_adam, no weight decay, no amsgrad)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
-                                                   float step_size, float beta1, float beta2, float eps,
-                                                   float bc2_sqrt) {
-  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
-  if (i >= n) return;
+__device__ __forceinline__ void adam_elem(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                          float* __restrict__ v, int64_t i, float step_size, float beta1, float beta2,
+                                          float eps, float bc2_sqrt) {
   float gi = g[i];
   float mi = m[i];
   mi = mi + (1.f - beta1) * (gi - mi);         // exp_avg.lerp_(grad, 1-beta1)
@@ -229,6 +235,89 @@ __global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const 
   v[i] = vi;
   float denom = sqrtf(vi) / bc2_sqrt + eps;
   p[i] = p[i] - step_size * (mi / denom);      // addcdiv_(exp_avg, denom, value=-step_size)
+}
+
+__global__ __launch_bounds__(TPB) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                   float step_size, float beta1, float beta2, float eps,
+                                                   float bc2_sqrt) {
+  int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  adam_elem(p, g, m, v, i, step_size, beta1, beta2, eps, bc2_sqrt);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// multi-tensor variants: ONE launch for all layers' weight and bias tensors (14 per decoder).  The segment table
+// travels as a kernel argument (<= 16 segments, ~1.5 KB); a block finds its segment by a short scan of the block
+// prefix, then works on 1024 consecutive elements of that tensor.  Per-element arithmetic = the single-tensor kernels'.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAXSEG = 16;
+struct AdaSegD {
+  const float* x;
+  const float* gy;
+  const float* alpha;
+  const float* delta;
+  const float* zp;
+  float* out;
+  int64_t n;
+  int row_len, per_row, soft;
+  float qmax, reg_weight;
+};
+struct AdaMulti {
+  AdaSegD s[MAXSEG];
+  int blk0[MAXSEG + 1];
+  int nseg;
+  float reg_b;
+};
+struct AdamSegD {
+  float* p;
+  const float* g;
+  float* m;
+  float* v;
+  int64_t n;
+};
+struct AdamMulti {
+  AdamSegD s[MAXSEG];
+  int blk0[MAXSEG + 1];
+  int nseg;
+};
+
+template <class T>
+__device__ __forceinline__ int find_seg(const T& t, int blk) {
+  int k = 0;
+  while (k + 1 < t.nseg && blk >= t.blk0[k + 1]) ++k;
+  return k;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(TPB) void adaround_multi_kernel(AdaMulti t) {
+  const int k = find_seg(t, blockIdx.x);
+  const AdaSegD& sg = t.s[k];
+  int64_t i = (int64_t)(blockIdx.x - t.blk0[k]) * (TPB * EPT) + threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e, i += TPB) {
+    if (i < sg.n) {
+      const int64_t row = sg.per_row ? i / sg.row_len : 0;
+      const float d = sg.delta[row], z = sg.zp[row];
+      if (BWD) {
+        sg.out[i] = ada_bwd_elem(sg.x[i], sg.gy[i], sg.alpha[i], d, z, sg.qmax, sg.reg_weight, t.reg_b);
+      } else {
+        float xq;
+        sg.out[i] = ada_fwd_elem(sg.x[i], sg.alpha[i], d, z, sg.qmax, sg.soft, xq);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void adam_multi_kernel(AdamMulti t, float step_size, float beta1, float beta2, float eps,
+                                                         float bc2_sqrt) {
+  const int k = find_seg(t, blockIdx.x);
+  const AdamSegD& sg = t.s[k];
+  int64_t i = (int64_t)(blockIdx.x - t.blk0[k]) * (TPB * EPT) + threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e, i += TPB)
+    if (i < sg.n) adam_elem(sg.p, sg.g, sg.m, sg.v, i, step_size, beta1, beta2, eps, bc2_sqrt);
 }
 
 inline dim3 row_grid(int64_t rows, int64_t row_len) {
@@ -330,6 +419,63 @@ int nq_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
   if (!p || !g || !m || !v || n <= 0) return NQ_ERR_INVALID;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, nq_s(stream), p, g, m, v, n,
                      step_size, beta1, beta2, eps, bc2_sqrt);
+  return nq_launch_status();
+}
+
+static int ada_multi(const nq_ada_seg* segs, int nseg, float reg_b, bool bwd, nq_stream_t stream) {
+  if (!segs || nseg <= 0) return NQ_ERR_INVALID;
+  for (int base = 0; base < nseg; base += MAXSEG) {
+    AdaMulti t;
+    t.nseg = (nseg - base < MAXSEG) ? nseg - base : MAXSEG;
+    t.reg_b = reg_b;
+    int blocks = 0;
+    for (int k = 0; k < t.nseg; ++k) {
+      const nq_ada_seg& h = segs[base + k];
+      if (!h.x || !h.alpha || !h.delta || !h.zp || !h.out || (bwd && !h.gy) || h.rows <= 0 || h.row_len <= 0 ||
+          h.row_len > 0x7fffffffLL)
+        return NQ_ERR_INVALID;
+      AdaSegD& d = t.s[k];
+      d.x = h.x; d.gy = h.gy; d.alpha = h.alpha; d.delta = h.delta; d.zp = h.zp; d.out = h.out;
+      d.n = h.rows * h.row_len; d.row_len = (int)h.row_len; d.per_row = h.per_row; d.soft = h.soft;
+      d.qmax = (float)(h.n_levels - 1); d.reg_weight = h.reg_weight;
+      t.blk0[k] = blocks;
+      blocks += (int)((d.n + TPB * EPT - 1) / (TPB * EPT));
+    }
+    t.blk0[t.nseg] = blocks;
+    if (bwd)
+      hipLaunchKernelGGL(adaround_multi_kernel<true>, dim3((unsigned)blocks), dim3(TPB), 0, nq_s(stream), t);
+    else
+      hipLaunchKernelGGL(adaround_multi_kernel<false>, dim3((unsigned)blocks), dim3(TPB), 0, nq_s(stream), t);
+  }
+  return nq_launch_status();
+}
+
+int nq_adaround_forward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream) {
+  return ada_multi(segs, nseg, 0.f, false, stream);
+}
+
+int nq_adaround_backward_multi(const nq_ada_seg* segs, int nseg, float reg_b, nq_stream_t stream) {
+  return ada_multi(segs, nseg, reg_b, true, stream);
+}
+
+int nq_adam_step_multi(const nq_adam_seg* segs, int nseg, float step_size, float beta1, float beta2, float eps,
+                       float bc2_sqrt, nq_stream_t stream) {
+  if (!segs || nseg <= 0) return NQ_ERR_INVALID;
+  for (int base = 0; base < nseg; base += MAXSEG) {
+    AdamMulti t;
+    t.nseg = (nseg - base < MAXSEG) ? nseg - base : MAXSEG;
+    int blocks = 0;
+    for (int k = 0; k < t.nseg; ++k) {
+      const nq_adam_seg& h = segs[base + k];
+      if (!h.p || !h.g || !h.m || !h.v || h.n <= 0) return NQ_ERR_INVALID;
+      t.s[k].p = h.p; t.s[k].g = h.g; t.s[k].m = h.m; t.s[k].v = h.v; t.s[k].n = h.n;
+      t.blk0[k] = blocks;
+      blocks += (int)((h.n + TPB * EPT - 1) / (TPB * EPT));
+    }
+    t.blk0[t.nseg] = blocks;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(TPB), 0, nq_s(stream), t, step_size, beta1, beta2,
+                       eps, bc2_sqrt);
+  }
   return nq_launch_status();
 }
 

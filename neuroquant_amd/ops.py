@@ -155,8 +155,40 @@ def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
                                  _stream()), "adam_step")
 
 
+def adaround_forward_multi(items):
+    """items: [(x, alpha, delta, zp, n_levels, soft)] -> [fake-quantised tensors], ONE launch for all of them
+    (same arithmetic as adaround_forward, bit for bit)."""
+    segs = (L.AdaSeg * len(items))()
+    outs = []
+    for sg, (x, alpha, delta, zp, n_levels, soft) in zip(segs, items):
+        x, alpha, delta, zp = _dev(x), _dev(alpha), _dev(delta), _dev(zp)
+        rows, rl, per_row = _rows(x, delta)
+        y = torch.empty_like(x)
+        outs.append(y)
+        sg.x, sg.gy, sg.alpha, sg.delta, sg.zp, sg.out = _p(x), None, _p(alpha), _p(delta), _p(zp), _p(y)
+        sg.rows, sg.row_len, sg.per_row, sg.n_levels, sg.soft, sg.reg_weight = rows, rl, per_row, n_levels, int(bool(soft)), 0.0
+    L.check(L.lib().nq_adaround_forward_multi(segs, len(items), _stream()), "adaround_forward_multi")
+    return outs
+
+
+def adaround_backward_multi(items, reg_b=0.0):
+    """items: [(x, gy, alpha, delta, zp, n_levels, reg_weight)] -> [d(alpha)] (+ regulariser gradient where
+    reg_weight != 0), ONE launch."""
+    segs = (L.AdaSeg * len(items))()
+    outs = []
+    for sg, (x, gy, alpha, delta, zp, n_levels, reg_weight) in zip(segs, items):
+        x, gy, alpha, delta, zp = _dev(x), _dev(gy), _dev(alpha), _dev(delta), _dev(zp)
+        rows, rl, per_row = _rows(x, delta)
+        da = torch.empty_like(alpha)
+        outs.append(da)
+        sg.x, sg.gy, sg.alpha, sg.delta, sg.zp, sg.out = _p(x), _p(gy), _p(alpha), _p(delta), _p(zp), _p(da)
+        sg.rows, sg.row_len, sg.per_row, sg.n_levels, sg.soft, sg.reg_weight = rows, rl, per_row, n_levels, 1, float(reg_weight)
+    L.check(L.lib().nq_adaround_backward_multi(segs, len(items), float(reg_b), _stream()), "adaround_backward_multi")
+    return outs
+
+
 class FusedAdam:
-    """torch.optim.Adam(params, lr) with default betas/eps, one nq_adam_step launch per tensor."""
+    """torch.optim.Adam(params, lr) with default betas/eps; all tensors updated by ONE nq_adam_step_multi launch."""
 
     def __init__(self, params, lr):
         self.params = [p for p in params]
@@ -169,13 +201,21 @@ class FusedAdam:
         for p in self.params:
             p.grad = None
 
-    def step(self, grads=None):
+    def step(self, grads=None, beta1=0.9, beta2=0.999, eps=1e-8):
         self.t += 1
-        for i, p in enumerate(self.params):
-            g = p.grad if grads is None else grads[i]
-            if g is None:
-                continue
-            adam_step(p.data, g, self.m[i], self.v[i], self.lr, self.t)
+        todo = [(p, (p.grad if grads is None else grads[i]), self.m[i], self.v[i]) for i, p in enumerate(self.params)]
+        todo = [t for t in todo if t[1] is not None]
+        if not todo:
+            return
+        segs = (L.AdamSeg * len(todo))()
+        keep = []
+        for sg, (p, g, m, v) in zip(segs, todo):
+            g = _dev(g).contiguous()
+            keep.append(g)
+            sg.p, sg.g, sg.m, sg.v, sg.n = _p(p.data), _p(g), _p(m), _p(v), p.numel()
+        bc1, bc2 = 1 - beta1 ** self.t, 1 - beta2 ** self.t
+        L.check(L.lib().nq_adam_step_multi(segs, len(todo), self.lr / bc1, beta1, beta2, eps, bc2 ** 0.5, _stream()),
+                "adam_step_multi")
 
 
 class _UAQFn(Function):

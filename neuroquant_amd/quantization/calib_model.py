@@ -106,6 +106,11 @@ class _Layer:
         self._finish(Wq, ops.adaround_forward(self.bias, bq.alpha.data, bq.delta.data, bq.zero_point, bq.n_levels,
                                               bq.soft_targets))
 
+    def ada_items(self):
+        wq, bq = self.m.weight_quantizer, self.m.bias_quantizer
+        return [(self.src, wq.alpha.data, wq.delta.data, wq.zero_point, wq.n_levels, wq.soft_targets),
+                (self.bias, bq.alpha.data, bq.delta.data, bq.zero_point, bq.n_levels, bq.soft_targets)]
+
     def _finish(self, Wq, b):
         self.W = (ops.fwht_channels(Wq, self.n, self.c_in) if self.hadamard else Wq).requires_grad_(True)
         self.b = b.requires_grad_(True)
@@ -169,23 +174,33 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                 reg_on = ada and not (count < loss_start)
                 if not reg_on:
                     b = 0
-                for L in layers:
-                    L.forward_ada() if ada else L.forward_uaq()
+                if ada:   # all 14 fake-quantised tensors in one launch
+                    fq = ops.adaround_forward_multi(
+                        [it for L in layers for it in L.ada_items()])
+                    for i, L in enumerate(layers):
+                        L._finish(fq[2 * i], fq[2 * i + 1])
+                else:
+                    for L in layers:
+                        L.forward_uaq()
                 img_out, _, _ = model(inputs)
                 rec = ops.l2_loss(img_out, img)
                 rec.backward()
                 if dp:  # data-parallel: one all-reduce over the raw conv weight+bias gradients
                     allreduce_mean_([t.grad for L in layers for t in (L.W, L.b)])
                 grads = []
-                for L in layers:
-                    gW, gb = L.grads()
-                    wq, bq = L.m.weight_quantizer, L.m.bias_quantizer
-                    if ada:
-                        grads.append(ops.adaround_backward(L.src, gW, wq.alpha.data, wq.delta.data, wq.zero_point,
-                                                           wq.n_levels, weight if reg_on else 0.0, b))
-                        grads.append(ops.adaround_backward(L.bias, gb, bq.alpha.data, bq.delta.data, bq.zero_point,
-                                                           bq.n_levels))
-                    else:
+                if ada:   # d(alpha) of all 14 tensors (+ regulariser gradient on the weights) in one launch
+                    items = []
+                    for L in layers:
+                        gW, gb = L.grads()
+                        wq, bq = L.m.weight_quantizer, L.m.bias_quantizer
+                        items.append((L.src, gW, wq.alpha.data, wq.delta.data, wq.zero_point, wq.n_levels,
+                                      weight if reg_on else 0.0))
+                        items.append((L.bias, gb, bq.alpha.data, bq.delta.data, bq.zero_point, bq.n_levels, 0.0))
+                    grads = ops.adaround_backward_multi(items, b)
+                else:
+                    for L in layers:
+                        gW, gb = L.grads()
+                        wq, bq = L.m.weight_quantizer, L.m.bias_quantizer
                         grads.append(ops.uaq_backward(L.src, gW, wq.delta.data, wq.zero_point, wq.n_levels))
                         grads.append(ops.uaq_backward(L.bias, gb, bq.delta.data, bq.zero_point, bq.n_levels))
                 want_log = recorder is not None or count % 500 == 0

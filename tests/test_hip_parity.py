@@ -704,3 +704,43 @@ def test_sensitivity_criterion_matches_reference(ops, golden, mode):
         assert abs(score - ref) <= 2e-3 * abs(ref), (score, ref)
         scores.append(score)
     assert (scores[0] < scores[1]) == (float(zo[f"{mode}0"]) < float(zo[f"{mode}1"]))   # same candidate wins
+
+
+# ------------------------------------------------------------------------------------------ multi-tensor launches
+def test_multi_tensor_kernels_equal_single_tensor_ones(ops):
+    """nq_adaround_{forward,backward}_multi / nq_adam_step_multi (one launch for all layers) vs the single-tensor entry
+    points: bit-identical, also past 16 segments (chunked launches) and with per-tensor regulariser weights."""
+    g = torch.Generator().manual_seed(11)
+    shapes = [(92, 16, 1, 1), (92,), (37, 5, 3, 3), (37,), (148, 44, 5, 5), (148,), (3, 37, 3, 3), (3,)] * 3   # 24 tensors
+    items_f, items_b, single_f, single_b = [], [], [], []
+    for i, shp in enumerate(shapes):
+        x = (torch.randn(shp, generator=g) * 0.2).to(DEV)
+        nl = 2 ** (2 + i % 7)
+        if len(shp) == 4:
+            d, zp = ops.scale_init_max(x, nl, True)
+        else:
+            d, zp = ops.scale_init_max(x, nl, False)
+        alpha = torch.randn(shp, generator=g).to(DEV) * 3
+        gy = torch.randn(shp, generator=g).to(DEV)
+        soft = (i % 3) != 0
+        regw = 0.01 if len(shp) == 4 else 0.0
+        items_f.append((x, alpha, d, zp, nl, soft))
+        items_b.append((x, gy, alpha, d, zp, nl, regw))
+        single_f.append(ops.adaround_forward(x, alpha, d, zp, nl, soft))
+        single_b.append(ops.adaround_backward(x, gy, alpha, d, zp, nl, regw, 7.3))
+    for a, b in zip(ops.adaround_forward_multi(items_f), single_f):
+        assert torch.equal(a, b)
+    for a, b in zip(ops.adaround_backward_multi(items_b, 7.3), single_b):
+        assert torch.equal(a, b)
+    # Adam: 3 steps, multi (FusedAdam) vs per-tensor adam_step
+    ps = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    ref = [p.clone() for p in ps]
+    ms, vs = [torch.zeros_like(p) for p in ps], [torch.zeros_like(p) for p in ps]
+    fa = ops.FusedAdam(ps, lr=0.003)
+    for t in range(1, 4):
+        gs = [torch.randn(p.shape, generator=g).to(DEV) for p in ps]
+        fa.step(gs)
+        for p, gr, m, v in zip(ref, gs, ms, vs):
+            ops.adam_step(p, gr, m, v, 0.003, t)
+    for a, b in zip(ps, ref):
+        assert torch.equal(a, b)
