@@ -312,6 +312,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     });
     return;
   }
+  if ((epi == NQ_EPI_PS || epi == NQ_EPI_PS_GELU) && r == 2 && (W & 1) == 0) {
+    // PixelShuffle(2) with 16-byte stores.  A lane's 4 registers are the 2x2 output block of its pixel; the even lane of
+    // a pixel pair takes both upper rows, the odd lane both lower rows (one quad_perm DPP exchange per value), so each
+    // lane issues ONE dwordx4 store per tensor instead of two dwordx2: the epilogue is bound by the number of store
+    // instructions, not by bytes (measured: time scales with the instruction count at equal bytes).
+    const bool want_act = (epi == NQ_EPI_PS_GELU);
+    const bool odd = (lane & 1) != 0;
+    const int C = Cout >> 2;
+    const int64_t W2 = (int64_t)W * 2;
+    auto xchg = [](float v) {
+      return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    };
+    steps3<0, MI>([&](auto mi_c) {
+      constexpr int mi = decltype(mi_c)::value;
+      const int co = cob + mi * 16;  // first of the lane's 4 channels (multiple of 4); the pair partner has the same co
+      const bool cok = co < Cout;
+      const float4 bv = (a.bias && cok) ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const int py = y0 + 2 * wave + (nb >> 1), px = x0 + (nb & 1) * 16 + l16;
+        const bool valid = cok && py < H && px < W;   // W even: both lanes of a pair agree
+        const f32x4 v4 = acc[mi][nb];
+        const float v0 = v4[0] + bv.x, v1 = v4[1] + bv.y, v2 = v4[2] + bv.z, v3 = v4[3] + bv.w;
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, d0 = v0, d1 = v1, d2 = v2, d3 = v3;  // PS: z = conv; PS_GELU: z = gelu'
+        if (want_act) {
+          nq_gelu_pair(v0, g0, d0); nq_gelu_pair(v1, g1, d1); nq_gelu_pair(v2, g2, d2); nq_gelu_pair(v3, g3, d3);
+        }
+        const int64_t o = (((int64_t)b * C + (co >> 2)) * (2 * H) + 2 * py + (odd ? 1 : 0)) * W2 + 2 * (px - (odd ? 1 : 0));
+        {
+          const float r0 = xchg(odd ? d0 : d2), r1 = xchg(odd ? d1 : d3);
+          const float4 out = odd ? make_float4(r0, r1, d2, d3) : make_float4(d0, d1, r0, r1);
+          if (valid) *reinterpret_cast<float4*>(a.z + o) = out;
+        }
+        if (want_act) {
+          const float r0 = xchg(odd ? g0 : g2), r1 = xchg(odd ? g1 : g3);
+          const float4 out = odd ? make_float4(r0, r1, g2, g3) : make_float4(g0, g1, r0, r1);
+          if (valid) *reinterpret_cast<float4*>(a.y + o) = out;
+        }
+      }
+    });
+    return;
+  }
   steps3<0, MI>([&](auto mi_c) {
     constexpr int mi = decltype(mi_c)::value;
     const int co = cob + mi * 16;  // first of the lane's 4 channels (multiple of 4)
