@@ -61,6 +61,15 @@ __device__ __forceinline__ void wg3_steps(F&& f) {
 // bijection works as long as A (dY) and B (x) agree; oct_of is its own inverse.
 __device__ __forceinline__ int oct_of(int kq) { return ((kq & 1) << 1) | (kq >> 1); }
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// {bf16(f0) in the low half, bf16(f1) in the high half}: one v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pk_bf16(float f0, float f1) {
+  bf16x2_t t = {(__bf16)f0, (__bf16)f1};
+  return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ float lo_as_f32(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float hi_as_f32(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+
 __device__ __forceinline__ unsigned split_word(float v) {  // {hi16, lo16}
   __bf16 h = (__bf16)v;
   __bf16 l = (__bf16)(v - (float)h);
@@ -139,6 +148,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float* __restrict__ dyp = a.dy + (int64_t)b * Cout * HW + (int64_t)y * W + x0;
     const float* __restrict__ xp = a.x + (int64_t)b * Cin * HW + (int64_t)y * W + x0;
     const bool seg_full = (x0 + SEG <= W);
+    if (y >= PAD && y + PAD < H && x0 >= PAD && x0 + SEG + PAD <= W) {
+      // interior segment (the common case): every halo element exists -> no per-element tests, no exec-mask branches
+#pragma unroll
+      for (int i = 0; i < DPT; ++i) {
+        const int e = tid + i * 256;
+        const int co = e >> 2, q8 = (e & 3) * 8;
+        f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (e < DITEMS && co0 + co < Cout) {
+          const float* p = dyp + (int64_t)(co0 + co) * HW + q8;
+          v0 = *reinterpret_cast<const f32x4_u*>(p);
+          v1 = *reinterpret_cast<const f32x4_u*>(p + 4);
+        }
+        dv[i][0] = v0;
+        dv[i][1] = v1;
+      }
+#pragma unroll
+      for (int i = 0; i < XPT4; ++i) {
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (xlds[i] >= 0) v = *reinterpret_cast<const f32x4_u*>(xp + xoff[i]);
+        xv[i] = v;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < DPT; ++i) {
       const int e = tid + i * 256;
@@ -194,9 +226,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           const float f0 = (j < 2) ? dv[i][0][2 * j] : dv[i][1][2 * j - 4];
           const float f1 = (j < 2) ? dv[i][0][2 * j + 1] : dv[i][1][2 * j - 3];
           s += f0 + f1;
-          const unsigned w0 = split_word(f0), w1 = split_word(f1);
-          hi[j] = (w0 >> 16) | (w1 & 0xffff0000u);
-          lo[j] = (w0 & 0xffffu) | (w1 << 16);
+          const unsigned h2 = pk_bf16(f0, f1);   // same values as split_word, packed pairwise: 6 VALU per 2 elements
+          hi[j] = h2;
+          lo[j] = pk_bf16(f0 - lo_as_f32(h2), f1 - hi_as_f32(h2));
         }
         db_part[i] += s;
         dz[oct_of(q) * MT + co] = hi;       // pixel octet q is held by lane group oct_of(q)
@@ -209,8 +241,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int cc = xrc[i] & 4095;
         unsigned* d = xw + xlds[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (cc + j < RW) d[j] = split_word(xv[i][j]);
+        for (int jp = 0; jp < 2; ++jp) {
+          const float f0 = xv[i][2 * jp], f1 = xv[i][2 * jp + 1];
+          const unsigned h2 = pk_bf16(f0, f1);
+          const unsigned l2 = pk_bf16(f0 - lo_as_f32(h2), f1 - hi_as_f32(h2));
+          const unsigned w0 = __builtin_amdgcn_perm(h2, l2, 0x05040100u);  // {hi16(f0) << 16 | lo16(f0)}
+          const unsigned w1 = __builtin_amdgcn_perm(h2, l2, 0x07060302u);  // same for f1
+          if constexpr (4 * Q == RW) {
+            d[2 * jp] = w0;
+            d[2 * jp + 1] = w1;
+          } else {
+            if (cc + 2 * jp < RW) d[2 * jp] = w0;
+            if (cc + 2 * jp + 1 < RW) d[2 * jp + 1] = w1;
+          }
+        }
       }
     }
   };
@@ -235,8 +279,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       u32x4 hi, lo;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        hi[j] = (w[2 * j] >> 16) | (w[2 * j + 1] & 0xffff0000u);
-        lo[j] = (w[2 * j] & 0xffffu) | (w[2 * j + 1] << 16);
+        hi[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x07060302u);  // {hi16(w0), hi16(w1) << 16}
+        lo[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x05040100u);  // {lo16(w0), lo16(w1) << 16}
       }
       bh[ni] = __builtin_bit_cast(bf16x8, hi);
       bl[ni] = __builtin_bit_cast(bf16x8, lo);
