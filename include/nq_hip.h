@@ -171,6 +171,14 @@ int nq_conv3_supported(int B, int Cin, int H, int W, int Cout, int k);
 int64_t nq_conv_forward3_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
 int64_t nq_conv3_weight_bytes(int Cin, int Cout, int k);
 int nq_weight_layout3(const float* w, void* wt3, int Cin, int Cout, int k, int transposed, nq_stream_t stream);
+/* several operands (all layers, forward and data-gradient) in ONE launch; `segs` is a host array, pointers inside are
+ * device pointers; Cin/Cout/transposed per segment as for nq_weight_layout3 */
+typedef struct nq_wl3_seg {
+  const float* w;
+  void* wt3;
+  int Cin, Cout, k, transposed;
+} nq_wl3_seg;
+int nq_weight_layout3_multi(const nq_wl3_seg* segs, int nseg, nq_stream_t stream);
 int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* y, float* z, const float* zprev, float* ws, int B,
                      int Cin, int H, int W, int Cout, int k, int r, int epilogue, nq_stream_t stream);
 

@@ -37,12 +37,15 @@ inline int nst_of(int k) { return k == 5 ? nq_conv3_nst_k5() : nq_conv3_nst_k3()
 // One thread per 16-byte fragment slot (c, s, tile, kq, co): 8 consecutive channels of one tap, split into bf16 hi/lo.
 // transposed = 0: logical conv == the stored conv, src(co, ch, tap) = w[co][ch][tap]
 // transposed = 1: data gradient, logical (Cin=Cout_w -> Cout=Cin_w): src(co, ch, tap) = w[ch][co][KK-1-tap]
-__global__ __launch_bounds__(256) void weight_layout3_kernel(const float* __restrict__ w, uint4* __restrict__ out, int Cin,
-                                                             int Cout, int KK, int NST, int nchunk, int co_tiles, int MT,
-                                                             int transposed) {
-  const int64_t slots = (int64_t)nchunk * NST * co_tiles * 4 * MT;
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= slots) return;
+struct WL3 {
+  const float* w;
+  uint4* out;
+  int Cin, Cout, KK, NST, nchunk, co_tiles, MT, transposed;
+  int64_t slots;
+};
+__device__ __forceinline__ void wl3_slot(const WL3& p, int64_t i) {
+  const int MT = p.MT, co_tiles = p.co_tiles, NST = p.NST, Cin = p.Cin, Cout = p.Cout, KK = p.KK;
+  const float* __restrict__ w = p.w;
   const int co_l = (int)(i % MT);
   const int kq = (int)((i / MT) % 4);
   const int tile = (int)((i / (4 * MT)) % co_tiles);
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(256) void weight_layout3_kernel(const float* __rest
       const int ch = ch0 + 2 * j + t;
       float x = 0.f;
       if (tap < KK && ch < Cin && co < Cout)
-        x = transposed ? w[((int64_t)ch * Cout + co) * KK + (KK - 1 - tap)] : w[((int64_t)co * Cin + ch) * KK + tap];
+        x = p.transposed ? w[((int64_t)ch * Cout + co) * KK + (KK - 1 - tap)] : w[((int64_t)co * Cin + ch) * KK + tap];
       v[t] = x;
     }
     __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1];
@@ -70,8 +73,27 @@ __global__ __launch_bounds__(256) void weight_layout3_kernel(const float* __rest
   const int64_t step = (int64_t)c * NST + s;
   const int64_t plane_stride = (int64_t)co_tiles * 4 * MT;
   const int64_t base = step * 2 * plane_stride + (int64_t)tile * 4 * MT + kq * MT + co_l;
-  out[base] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-  out[base + plane_stride] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  p.out[base] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+  p.out[base + plane_stride] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+__global__ __launch_bounds__(256) void weight_layout3_kernel(WL3 p) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < p.slots) wl3_slot(p, i);
+}
+
+// all layers' operands (forward and data-gradient) in ONE launch: the table travels as a kernel argument
+constexpr int WL3_MAXSEG = 16;
+struct WL3Multi {
+  WL3 s[WL3_MAXSEG];
+  int blk0[WL3_MAXSEG + 1];
+  int nseg;
+};
+__global__ __launch_bounds__(256) void weight_layout3_multi_kernel(WL3Multi t) {
+  int k = 0;
+  while (k + 1 < t.nseg && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
+  const int64_t i = (int64_t)(blockIdx.x - t.blk0[k]) * 256 + threadIdx.x;
+  if (i < t.s[k].slots) wl3_slot(t.s[k], i);
 }
 
 // split-K of the forward / data-gradient kernel over 16-channel chunks when the pixel x channel grid alone cannot fill
@@ -177,13 +199,38 @@ int64_t nq_conv3_weight_bytes(int Cin, int Cout, int k) {
 
 // w: OIHW weight tensor of the STORED conv (Cout_w, Cin_w, k, k).  transposed = 0 -> operand of the forward conv
 // (Cin = Cin_w, Cout = Cout_w); transposed = 1 -> operand of its data gradient (Cin = Cout_w, Cout = Cin_w).
+static bool wl3_fill(WL3& p, const float* w, void* wt3, int Cin, int Cout, int k, int transposed) {
+  if (!w || !wt3 || !(k == 3 || k == 5) || Cin <= 0 || Cout <= 0) return false;
+  const int mi = pick_mi3(Cout);
+  p.w = w; p.out = reinterpret_cast<uint4*>(wt3);
+  p.Cin = Cin; p.Cout = Cout; p.KK = k * k; p.NST = nst_of(k);
+  p.MT = 16 * mi; p.co_tiles = (Cout + p.MT - 1) / p.MT; p.nchunk = (Cin + CC - 1) / CC; p.transposed = transposed;
+  p.slots = (int64_t)p.nchunk * p.NST * p.co_tiles * 4 * p.MT;
+  return true;
+}
+
 int nq_weight_layout3(const float* w, void* wt3, int Cin, int Cout, int k, int transposed, nq_stream_t stream) {
-  if (!w || !wt3 || !(k == 3 || k == 5) || Cin <= 0 || Cout <= 0) return NQ_ERR_INVALID;
-  const int mi = pick_mi3(Cout), mt = 16 * mi, nst = nst_of(k);
-  const int co_tiles = (Cout + mt - 1) / mt, nchunk = (Cin + CC - 1) / CC;
-  const int64_t slots = (int64_t)nchunk * nst * co_tiles * 4 * mt;
-  hipLaunchKernelGGL(weight_layout3_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, nq_s(stream), w,
-                     reinterpret_cast<uint4*>(wt3), Cin, Cout, k * k, nst, nchunk, co_tiles, mt, transposed);
+  WL3 p;
+  if (!wl3_fill(p, w, wt3, Cin, Cout, k, transposed)) return NQ_ERR_INVALID;
+  hipLaunchKernelGGL(weight_layout3_kernel, dim3((unsigned)((p.slots + 255) / 256)), dim3(256), 0, nq_s(stream), p);
+  return nq_launch_status();
+}
+
+int nq_weight_layout3_multi(const nq_wl3_seg* segs, int nseg, nq_stream_t stream) {
+  if (!segs || nseg <= 0) return NQ_ERR_INVALID;
+  for (int base = 0; base < nseg; base += WL3_MAXSEG) {
+    WL3Multi t;
+    t.nseg = (nseg - base < WL3_MAXSEG) ? nseg - base : WL3_MAXSEG;
+    int blocks = 0;
+    for (int i = 0; i < t.nseg; ++i) {
+      const nq_wl3_seg& h = segs[base + i];
+      if (!wl3_fill(t.s[i], h.w, h.wt3, h.Cin, h.Cout, h.k, h.transposed)) return NQ_ERR_INVALID;
+      t.blk0[i] = blocks;
+      blocks += (int)((t.s[i].slots + 255) / 256);
+    }
+    t.blk0[t.nseg] = blocks;
+    hipLaunchKernelGGL(weight_layout3_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, nq_s(stream), t);
+  }
   return nq_launch_status();
 }
 

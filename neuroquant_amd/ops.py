@@ -23,11 +23,19 @@ def _stream():
 
 # ---- optional per-launch timing with HIP events on the launch stream (bench.py's roofline object) ----
 _PROF = None
+_PROF_ON = True
 
 
 def profile_start():
-    global _PROF
-    _PROF = {}
+    global _PROF, _PROF_ON
+    _PROF, _PROF_ON = {}, True
+
+
+def profile_sample(on: bool):
+    """Pause / resume recording while a profile is open (bench.py times every N-th step only: each event record is a
+    marker packet in the queue, 50 of them per step cost ~4 % throughput)."""
+    global _PROF_ON
+    _PROF_ON = bool(on)
 
 
 def profile_stop():
@@ -39,7 +47,7 @@ def profile_stop():
 
 
 def _timed(key, fn):
-    if _PROF is None:
+    if _PROF is None or not _PROF_ON:
         return fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
@@ -372,6 +380,22 @@ def weight_layout3(w, transposed=False):
     return buf
 
 
+def weight_layout3_multi(items):
+    """items: [(w, transposed)] -> [operand buffers], ONE launch (same bytes as weight_layout3 per item)."""
+    segs = (L.WL3Seg * len(items))()
+    outs = []
+    for sg, (w, transposed) in zip(segs, items):
+        w = _dev(w)
+        cw_out, cw_in, k, _ = w.shape
+        cin, cout = (cw_out, cw_in) if transposed else (cw_in, cw_out)
+        buf = torch.empty(L.lib().nq_conv3_weight_bytes(cin, cout, k), device=w.device, dtype=torch.uint8)
+        outs.append(buf)
+        sg.w, sg.wt3, sg.Cin, sg.Cout, sg.k, sg.transposed = _p(w), _p(buf), cin, cout, k, int(bool(transposed))
+    if items:
+        L.check(L.lib().nq_weight_layout3_multi(segs, len(items), _stream()), "weight_layout3_multi")
+    return outs
+
+
 def conv3_forward_raw(x, wt3, bias, cout, k, epilogue, r, zprev=None):
     """bf16x3 counterpart of conv_forward_raw (same outputs)."""
     B, cin, H, W = x.shape
@@ -642,15 +666,31 @@ class _DecoderStackFn(Function):
         saved_in, saved_z, metas = [], [], []
         in_gelu = False      # (kept in the metas for the generic kernels' GELU-on-load option; unused by this schedule)
         zprev = None         # gelu'(pre-activation) behind x, saved by the producing epilogue
+        # pre-pass over the static shapes: which layers run on the bf16x3 kernels (forward / data gradient); all their
+        # pre-split operands are then built by ONE launch before the first convolution
+        Bx, Hx, Wx = x.shape[0], x.shape[2], x.shape[3]
+        plan, items = [], []
+        for l, (k, r, act) in enumerate(spec.layers):
+            W = _dev(wb[2 * l], "weight")
+            cout, cin = W.shape[0], W.shape[1]
+            use3 = spec.precision == "bf16x3" and conv3_supported(Bx, cin, Hx, Wx, cout, k)
+            use3_bwd = spec.precision == "bf16x3" and l > 0 and conv3_supported(Bx, cout, Hx, Wx, cin, k)
+            plan.append((use3, use3_bwd, len(items) if use3 else -1, len(items) + int(use3) if use3_bwd else -1))
+            if use3:
+                items.append((W, False))
+            if use3_bwd:
+                items.append((W, True))
+            if l == 0:
+                Hx, Wx = Hx * spec.fc_hw[0], Wx * spec.fc_hw[1]
+            Hx, Wx = Hx * r, Wx * r
+        operands = weight_layout3_multi(items)
         for l, (k, r, act) in enumerate(spec.layers):
             W = _dev(wb[2 * l], "weight")
             b = _dev(wb[2 * l + 1], "bias") if wb[2 * l + 1] is not None else None
             cout, cin = W.shape[0], W.shape[1]
-            Bx, _, Hx, Wx = x.shape
-            use3 = spec.precision == "bf16x3" and not in_gelu and conv3_supported(Bx, cin, Hx, Wx, cout, k)
-            use3_bwd = spec.precision == "bf16x3" and l > 0 and conv3_supported(Bx, cout, Hx, Wx, cin, k)
+            use3, use3_bwd, i_f, i_b = plan[l]
             if use3:
-                wt3 = weight_layout3(W)
+                wt3 = operands[i_f]
                 wt, dims = None, None
             else:
                 wt, dims, _, _ = weight_layouts(W, need_bwd=False)
@@ -672,7 +712,7 @@ class _DecoderStackFn(Function):
                 y, z = conv_forward_raw(x, wt, dims, b, cout, k, epi, r, in_gelu=in_gelu)
             saved_in.append(x)
             saved_z.append(zprev)
-            metas.append((k, r, act, cout, cin, in_gelu, wbk, dims_b, b is not None, W if use3_bwd else None))
+            metas.append((k, r, act, cout, cin, in_gelu, wbk, dims_b, b is not None, operands[i_b] if use3_bwd else None))
             if epi == EPI_PS_GELU:
                 x, zprev, in_gelu = y, z, False
             elif epi == EPI_PS:
@@ -736,7 +776,7 @@ class _DecoderStackFn(Function):
                 raise NotImplementedError("PixelShuffle without activation between decoder layers")
             # the layer below ends in GELU: d(pre-activation) = dgrad * gelu'(z), stored as ITS conv-output gradient
             if W3 is not None:
-                dconv, _ = conv3_forward_raw(dconv, weight_layout3(W3, transposed=True), None, cin, k, epi_b, r_b, zprev=zp)
+                dconv, _ = conv3_forward_raw(dconv, W3, None, cin, k, epi_b, r_b, zprev=zp)   # W3 = pre-built transposed operand
             else:
                 dconv, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, epi_b, r_b, zprev=zp)
             if not actp:

@@ -7,4 +7,4 @@ tot = sum(r["total_ms"] for r in rows)
 steps = max(r["launches"] for r in rows)
 for r in rows:
     print(f'{r["kernel"]:12s} k{r["k"]} {r["cin"]:4d}->{r["cout"]:4d} {r["H"]:4d}x{r["W"]:<4d} n={r["launches"]:3d} avg {r["avg_ms"]:.3f} ms  {r["tflops"]:6.1f} TF')
-print(f"conv total per step (approx, /{steps}): {tot/steps:.3f} ms")
+print(f"conv total per profiled step (/{steps}): {tot/steps:.3f} ms")
