@@ -31,6 +31,10 @@ HNERV_3M = dict(crop_h=640, crop_w=1280, diff_enc=False, stage_block=1, enc_stri
                 dec_kernels=[1, 3, 5, 5, 5], dec_strides=[5, 4, 4, 2, 2], dec_norm="none", dec_acts="gelu",
                 out_bias="tanh")
 BITS = [6, 5, 4, 5, 5, 6, 6]
+# --workload nerv: BASELINE configs[2] (NeRV Bunny_1280x640_3M + Hadamard); not the headline line, a secondary check
+NERV_3M = dict(crop_h=640, crop_w=1280, diff_enc=False, base=1.25, level=80, channel_reduce=2, channel_lbound=24,
+               dec_in_channel=145, dec_kernels=[3, 3, 3, 3, 3], dec_strides=[5, 4, 4, 2, 2], dec_norm="none",
+               dec_acts="gelu", out_bias="tanh")
 # /opt/skills/guides/MI355X_MICROARCH.md, Matrix cores: fp32-input MFMA 157.3 TF; dense BF16 MFMA ~2.5 PF.  The bf16x3
 # kernels spend three BF16 MFMAs per fp32-equivalent product (hi*hi + hi*lo + lo*hi), so their ceiling in ALGORITHMIC
 # (fp32-equivalent) FLOP/s is 2500/3.
@@ -40,10 +44,10 @@ PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 FLAGS = dict(weight=0.01, b_range=(20, 2), lr=0.003)
 
 
-def build_model(seed=903):
-    from neuroquant_amd.models import HNeRV
+def build_model(seed=903, workload="hnerv"):
+    from neuroquant_amd.models import HNeRV, NeRV
     torch.manual_seed(seed)
-    model = HNeRV(HNERV_3M)
+    model = HNeRV(HNERV_3M) if workload == "hnerv" else NeRV(NERV_3M)
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():  # decoder: variance-preserving init so activations / gradients have trained-model scale
         for name, p in model.named_parameters():
@@ -64,6 +68,8 @@ def main():
     ap.add_argument("--frames", type=int, default=132)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--workload", choices=("hnerv", "nerv"), default="hnerv",
+                    help="hnerv = the headline config (default); nerv = NeRV-3M + Hadamard (BASELINE configs[2]), no cpu baseline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,15 +95,19 @@ def main():
     n_frames = max(args.frames // gB * gB, gB)
 
     # ---- workload, resident in HBM ----
-    model = build_model()
+    nerv = args.workload == "nerv"
+    model = build_model(workload=args.workload)
     sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("encoder")}
     model = model.to(dev)
     frames_u8 = synthetic_frames(n_frames, 640, 1280, seed=903, device=dev)
     cache = FrameCache(frames_u8)
     with torch.no_grad():
-        emb = torch.cat([model.encode(cache.batch(torch.arange(i, min(i + 4, n_frames), device=dev)))
-                         for i in range(0, n_frames, 4)])
-    qnn = QuantModel(model, hadamard=False, weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
+        if nerv:
+            emb = model.encode(torch.arange(n_frames, device=dev).float() / n_frames)
+        else:
+            emb = torch.cat([model.encode(cache.batch(torch.arange(i, min(i + 4, n_frames), device=dev)))
+                             for i in range(0, n_frames, 4)])
+    qnn = QuantModel(model, hadamard=nerv, weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
     avg_bits = qnn.set_bitwidth(BITS)
     qnn.eval()
     qnn.set_quant_state(True)
@@ -133,7 +143,7 @@ def main():
             t["t1"] = time.perf_counter()
             t["prof"] = ops.profile_stop() if not os.environ.get("NQ_BENCH_NOPROF") else {}
 
-    model_reconstruction(qnn, cali_data=emb, gt=loader, arch="hnerv", batch_size=gB, iters=iters, hadamard=False,
+    model_reconstruction(qnn, cali_data=emb, gt=loader, arch=args.workload, batch_size=gB, iters=iters, hadamard=nerv,
                          warmup=0.0, max_steps=steps_total, step_hook=hook, **FLAGS)
     if "t1" not in t:
         hook(steps_total)
@@ -191,7 +201,7 @@ def main():
 
     # ---- CPU baseline: the oracle (restatement of the reference's PyTorch-CPU path) on this box's host cores ----
     cpu = None
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not nerv:
         cpu = cpu_baseline(sd_cpu, frames_u8[:8], emb[:8], args.cpu_iters)
 
     value = K * world / elapsed
@@ -202,7 +212,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32 operands split into bf16 hi+lo, 3 BF16 MFMAs per product, fp32 accumulate (bf16x3); fp32 MFMA on small layers",
         "data": "synthetic",
-        "config": {"workload": "HNeRV Bunny_1280x640_3M, channel_wise, bits 6 5 4 5 5 6 6, phase-2 (AdaRound) iteration",
+        "config": {"workload": ("NeRV Bunny_1280x640_3M + Hadamard" if nerv else "HNeRV Bunny_1280x640_3M")
+                   + ", channel_wise, bits 6 5 4 5 5 6 6, phase-2 (AdaRound) iteration",
                    "per_gpu_batch": B, "global_batch": gB, "frames": n_frames, "avg_bits": avg_bits,
                    "parallelism": f"dp{world}"},
         "roofline": roofline,
