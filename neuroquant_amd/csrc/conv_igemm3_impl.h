@@ -47,6 +47,7 @@ struct Conv3Args {
   int B, Cin, H, W, Cout, r, epi, tiles_x, nchunk, co_tiles;
   int nsplit, per_split;  // split-K over channel chunks: blockIdx.z = b*nsplit + split, chunks [split*per, +per)
   float* slab;            // [nsplit][B][Cout][H][W] raw partial sums when nsplit > 1 (nq_conv_splitk_finish adds them)
+  int lds_epi;            // the launch reserved MT*1024 B of LDS: the data-gradient epilogue may transpose through it
 };
 
 constexpr int KS = NQ_KS;
@@ -281,6 +282,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     return;
   }
   const int epi = a.epi;
+  if (epi == NQ_EPI_DGRAD_GELU && a.lds_epi && (W & 3) == 0) {
+    // Wide variant (the epilogue is bound by the NUMBER of global load/store instructions, not by bytes): every wave
+    // transposes its 2 x 32 pixel x MT channel tile through its own LDS region so that a lane then owns 4 consecutive
+    // pixels of one channel: ONE 16-byte load of gelu' and, for r = 2, TWO 8-byte stores (even / odd pixels go to
+    // different un-shuffled planes) per 4 outputs, instead of 4 loads + 4 stores.  LDS is free here: the K loop ended
+    // with a barrier.  Region: [MT][2 rows][32 px] floats = MT*256 B per wave.
+    float* const stage = reinterpret_cast<float*>(smem) + wave * (MT * 64);
+    steps3<0, MI>([&](auto mi_c) {
+      constexpr int mi = decltype(mi_c)::value;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int cl = mi * 16 + 4 * kq + reg;
+        const float bv = (a.bias && co0 + cl < Cout) ? a.bias[co0 + cl] : 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) stage[cl * 64 + (nb >> 1) * 32 + (nb & 1) * 16 + l16] = acc[mi][nb][reg] + bv;
+      }
+    });
+    const int Wo = W / r;
+    const int plane = (int)(HW / rr);
+#pragma unroll
+    for (int it = 0; it < MT / 4; ++it) {
+      const int e = it * 64 + lane;
+      const int q = e & 7, row = (e >> 3) & 1, cl = e >> 4;
+      const int cc = co0 + cl, py = y0 + 2 * wave + row, px0 = x0 + q * 4;
+      if (cc >= Cout || py >= H || px0 >= W) continue;   // W % 4 == 0: a quad is inside or outside as a whole
+      f32x4 v = *reinterpret_cast<const f32x4*>(stage + cl * 64 + row * 32 + q * 4);
+      const int64_t cbase = ((int64_t)b * Cout + cc) * HW;
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(a.zprev + cbase + (int64_t)py * W + px0);
+      v = v * d4;
+      float* __restrict__ yo = a.y + cbase;
+      if (r == 2) {
+        const int o = ((py & 1) * 2) * plane + (py >> 1) * Wo + (px0 >> 1);
+        *reinterpret_cast<float2*>(yo + o) = make_float2(v[0], v[2]);
+        *reinterpret_cast<float2*>(yo + o + plane) = make_float2(v[1], v[3]);
+      } else if (r == 4) {
+        const int o = ((py & 3) * 4) * plane + (py >> 2) * Wo + (px0 >> 2);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yo[o + j * plane] = v[j];
+      } else {
+        const int yq = py / r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int px = px0 + j, xq = px / r;
+          yo[((py - yq * r) * r + (px - xq * r)) * plane + yq * Wo + xq] = v[j];
+        }
+      }
+    }
+    return;
+  }
   if (epi == NQ_EPI_DGRAD_GELU) {
     // data gradient w.r.t. the pre-activation below: acc * gelu'(z) (zprev = the derivative saved by the forward
     // epilogue, same NCHW layout as this conv's output), stored un-shuffled: channel c*r*r + (y%r)*r + x%r at
@@ -415,15 +465,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 template <int MI>
-int launch_igemm3(const Conv3Args& a, int tiles, hipStream_t st) {
+int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
   constexpr int MT = 16 * MI;
   size_t lds = (size_t)(PATCH_U4 + 2 * 2 * 4 * MT) * 16;
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
+  Conv3Args a = a_in;
+  a.lds_epi = 0;
+  if (a.epi == NQ_EPI_DGRAD_GELU && a.nsplit == 1 && MI <= 4) {   // 4 waves x [MT][64] floats for the wide epilogue
+    a.lds_epi = 1;
+    if (lds < (size_t)MT * 1024) lds = (size_t)MT * 1024;
+  }
+  static size_t attr_lds = 64 * 1024;  // more dynamic LDS than the default limit needs an explicit opt-in
+  if (lds > attr_lds) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm3_kernel<MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess)
       return NQ_ERR_LAUNCH;
-    attr_set = true;
+    attr_lds = lds;
   }
   hipLaunchKernelGGL(conv_igemm3_kernel<MI>, dim3((unsigned)tiles, (unsigned)a.co_tiles, (unsigned)(a.B * a.nsplit)), dim3(256),
                      lds, st, a);
