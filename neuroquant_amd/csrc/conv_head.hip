@@ -25,8 +25,12 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                                                        int H, int W, int CO, int epi, int tiles_x) {
   constexpr int KK = KS * KS, PAD = KS / 2;
   constexpr int TH = 16, TW = 64, CCH = 4;
-  constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
-  constexpr int PWS = (PW + 3) / 4 * 4;  // 16-byte aligned rows
+  constexpr int PH = TH + KS - 1;
+  // LDS rows: [OFF-PAD, OFF) left halo | [OFF, OFF+64) interior (16-byte aligned) | [OFF+64, OFF+64+PAD) right halo.
+  // The interior is staged with 16-byte global loads / ds_write_b128 (4.5 per thread per chunk instead of 18 scalar
+  // loads: the kernel is bound by the number of memory instructions), only the 2*PAD halo columns are scalar.
+  constexpr int OFF = 4, PWS = 72;
+  constexpr int NQUAD = CCH * PH * (TW / 4), NHALO = CCH * PH * 2 * PAD;
   __shared__ __attribute__((aligned(16))) float patch[CCH * PH * PWS];
 
   const int tid = threadIdx.x;
@@ -35,6 +39,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   const int x0 = tile_x * TW, y0 = tile_y * TH, b = blockIdx.y;
   const int64_t HW = (int64_t)H * W;
   const float* __restrict__ xb = x + (int64_t)b * Cin * HW;
+  const bool w4 = (W & 3) == 0;
 
   float acc[MAXCO][4];
 #pragma unroll
@@ -44,13 +49,34 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 
   for (int c0 = 0; c0 < Cin; c0 += CCH) {
     __syncthreads();
-    for (int e = tid; e < CCH * PH * PW; e += 256) {
-      int ci = e / (PH * PW), rem = e - ci * (PH * PW);
-      int r = rem / PW, c = rem - r * PW;
-      int gy = y0 - PAD + r, gx = x0 - PAD + c, cig = c0 + ci;
-      float v = 0.f;
-      if (cig < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) v = xb[(int64_t)cig * HW + (int64_t)gy * W + gx];
-      patch[(ci * PH + r) * PWS + c] = v;
+    for (int e = tid; e < NQUAD; e += 256) {
+      const int ci = e / (PH * (TW / 4)), rem = e - ci * (PH * (TW / 4));
+      const int r = rem / (TW / 4), q = rem - r * (TW / 4);
+      const int gy = y0 - PAD + r, gx = x0 + 4 * q, cig = c0 + ci;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cig < Cin && gy >= 0 && gy < H && gx < W) {
+        const float* p = xb + (int64_t)cig * HW + (int64_t)gy * W + gx;
+        if (w4) {
+          v = *reinterpret_cast<const float4*>(p);
+        } else {
+          v.x = p[0];
+          if (gx + 1 < W) v.y = p[1];
+          if (gx + 2 < W) v.z = p[2];
+          if (gx + 3 < W) v.w = p[3];
+        }
+      }
+      *reinterpret_cast<float4*>(patch + (ci * PH + r) * PWS + OFF + 4 * q) = v;
+    }
+    if constexpr (PAD > 0) {
+      for (int e = tid; e < NHALO; e += 256) {
+        const int ci = e / (PH * 2 * PAD), rem = e - ci * (PH * 2 * PAD);
+        const int r = rem / (2 * PAD), h = rem - r * (2 * PAD);
+        const int c = (h < PAD) ? h - PAD : TW + (h - PAD);   // column relative to x0: [-PAD, 0) or [TW, TW+PAD)
+        const int gy = y0 - PAD + r, gx = x0 + c, cig = c0 + ci;
+        float v = 0.f;
+        if (cig < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) v = xb[(int64_t)cig * HW + (int64_t)gy * W + gx];
+        patch[(ci * PH + r) * PWS + OFF + c] = v;
+      }
     }
     __syncthreads();
     const int cmax = min(CCH, Cin - c0);
@@ -59,7 +85,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 #pragma unroll
       for (int kh = 0; kh < KS; ++kh) {
         float in[4 + KS - 1];
-        const float* pr = patch + (ci * PH + row + kh) * PWS + c4;
+        const float* pr = patch + (ci * PH + row + kh) * PWS + (OFF - PAD) + c4;
 #pragma unroll
         for (int j = 0; j < 4 + KS - 1; ++j) in[j] = pr[j];
 #pragma unroll
