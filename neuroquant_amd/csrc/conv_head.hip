@@ -131,6 +131,12 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
   constexpr int PWS = (PW + 3) / 4 * 4;
   __shared__ __attribute__((aligned(16))) float patch[MAXCO * PH * PWS];
+  // weights of one output channel ci, contiguous: wl[ci][co*KK + tap] (row padded to a multiple of 4 floats).  The
+  // operand arrives k-major ([co*KK + tap][ld]): reading it per ci would be MAXCO*KK separate scalar loads; from LDS it is
+  // MAXCO*KK/4 broadcast ds_read_b128.
+  constexpr int WROW = (MAXCO * KK + 3) / 4 * 4;
+  constexpr int WL_MAX = 64;   // output channels cached per pass (64 * 112 * 4 B = 28 KB for k = 5)
+  __shared__ __attribute__((aligned(16))) float wl[WL_MAX * WROW];
 
   const int tid = threadIdx.x;
   const int row = tid >> 4, c4 = (tid & 15) * 4;
@@ -158,19 +164,29 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
       for (int j = 0; j < 4 + KS - 1; ++j) nb[co][kh][j] = (co < CO) ? patch[(co * PH + row + kh) * PWS + c4 + j] : 0.f;
 
   const int gy = y0 + row, gx0 = x0 + c4;
-  if (gy >= H || gx0 >= W) return;
+  const bool active = (gy < H && gx0 < W);   // inactive threads still help staging the weights and join the barriers
   const bool full = (gx0 + 3 < W);
   for (int ci = 0; ci < Cin; ++ci) {
+    if (ci % WL_MAX == 0) {   // (re)fill the weight cache for output channels [ci, ci + WL_MAX)
+      __syncthreads();
+      const int nci = min(WL_MAX, Cin - ci);
+      for (int e = tid; e < nci * WROW; e += 256) {
+        const int cl = e / WROW, j = e - cl * WROW;   // j = co*KK + tap
+        wl[e] = (j < CO * KK) ? wt[(int64_t)j * ld + ci + cl] : 0.f;
+      }
+      __syncthreads();
+    }
+    if (!active) continue;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ wrow = wl + (ci % WL_MAX) * WROW;
 #pragma unroll
     for (int co = 0; co < MAXCO; ++co) {
       if (co < CO) {
-        const float* __restrict__ wc = wt + (int64_t)co * KK * ld + ci;
 #pragma unroll
         for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
           for (int kw = 0; kw < KS; ++kw) {
-            const float wv = wc[(kh * KS + kw) * ld];  // wave-uniform -> scalar load
+            const float wv = wrow[co * KK + kh * KS + kw];  // same address in every lane: LDS broadcast
 #pragma unroll
             for (int p = 0; p < 4; ++p) acc[p] = fmaf(wv, nb[co][kh][p + kw], acc[p]);
           }
