@@ -822,6 +822,19 @@ def l2_loss(pred, tgt):
     return _L2LossFn.apply(pred, tgt)
 
 
+def l2_loss_and_grad(pred, tgt):
+    """(loss, d loss / d pred) from ONE kernel, outside autograd: `pred.backward(dpred)` then feeds the decoder node
+    directly (no ones-tensor, no elementwise multiply by the upstream gradient)."""
+    pred_d, tgt = _dev(pred.detach(), "pred"), _dev(tgt, "tgt")
+    n = pred_d.numel()
+    loss = torch.empty((), device=pred_d.device, dtype=torch.float32)
+    dpred = torch.empty_like(pred_d)
+    ws = torch.empty(L.lib().nq_reduce_ws_floats(n), device=pred_d.device, dtype=torch.float32)
+    L.check(L.lib().nq_l2_loss(_p(pred_d), _p(tgt), _p(loss), _p(dpred), _p(ws), n, n // pred_d.shape[1], 1.0, _stream()),
+            "l2_loss")
+    return loss, dpred
+
+
 def frame_psnr(out, gt):
     """per-frame PSNR (reference utils.py:148-151): -10*log10(mean((out-gt)^2) + 1e-9)."""
     out, gt = _dev(out.detach()), _dev(gt.detach())

@@ -183,8 +183,8 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                     for L in layers:
                         L.forward_uaq()
                 img_out, _, _ = model(inputs)
-                rec = ops.l2_loss(img_out, img)
-                rec.backward()
+                rec, dimg = ops.l2_loss_and_grad(img_out, img)   # lp_loss p=2 (quantizer.py:66-71) and its gradient
+                img_out.backward(dimg)
                 if dp:  # data-parallel: one all-reduce over the raw conv weight+bias gradients
                     allreduce_mean_([t.grad for L in layers for t in (L.W, L.b)])
                 grads = []

@@ -134,9 +134,10 @@ class CacheLoader:
         # this rank's slice of every batch goes to the device ONCE per epoch: a per-batch pageable H2D copy would
         # block the host on the stream every iteration
         mine = sel[:, self.rank * per:(self.rank + 1) * per].contiguous().to(dev)
+        norm = mine.float() / self.n_total           # once per epoch; the per-batch rows are views
         for i in range(mine.shape[0]):
             idx = mine[i]
-            yield {'img': self.cache.batch(idx), 'idx': idx, 'norm_idx': idx.float() / self.n_total}
+            yield {'img': self.cache.batch(idx), 'idx': idx, 'norm_idx': norm[i]}
 
 
 def allreduce_mean_(tensors, group=None):
