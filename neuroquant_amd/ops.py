@@ -420,12 +420,13 @@ def conv_wgrad3_supported(B, cin, H, W, cout, k):
     return bool(L.lib().nq_conv_wgrad3_supported(B, cin, H, W, cout, k))
 
 
-def conv_wgrad3_raw(x, dy, cout, k, want_db):
-    """bf16x3 counterpart of conv_wgrad_raw."""
+def conv_wgrad3_raw(x, dy, cout, k, want_db, out=None):
+    """bf16x3 counterpart of conv_wgrad_raw.  out = (dw, db) pre-allocated contiguous outputs (views of a flat
+    gradient arena) or None."""
     B, cin, H, W = x.shape
     ws = torch.empty(L.lib().nq_conv_wgrad3_ws_floats(B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
-    dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32)
-    db = torch.empty(cout, device=x.device, dtype=torch.float32) if want_db else None
+    dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32) if out is None else out[0]
+    db = (torch.empty(cout, device=x.device, dtype=torch.float32) if out is None else out[1]) if want_db else None
     _timed(("conv_wgrad3", k, cin, cout, H, W, B, 0),
            lambda: L.check(L.lib().nq_conv_wgrad3(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k, _stream()),
                            "conv_wgrad3"))
@@ -441,7 +442,7 @@ def channel_sum(x):
     return out
 
 
-def conv_wgrad_swapped3(x, dy, cout, k, want_db):
+def conv_wgrad_swapped3(x, dy, cout, k, want_db, out=None):
     """Weight gradient of a conv with very few OUTPUT channels (the 3-channel head) by swapping operand roles:
     R[ci][(co,kh,kw)] = sum_p x[ci][p] * dy[co][p + tap]  is the weight gradient of the conv  dy -> x-channels, and
     dW[co][ci][kh][kw] = R[ci][co][K-1-kh][K-1-kw].  The big tensor (x, 242 MB) is then the un-shifted GEMM operand
@@ -449,15 +450,21 @@ def conv_wgrad_swapped3(x, dy, cout, k, want_db):
     3(->16) x 333(->384)."""
     cin = x.shape[1]
     r, _ = conv_wgrad3_raw(dy, x, cin, k, False)
-    dw = r.permute(1, 0, 2, 3).flip(2, 3).contiguous()
-    return dw, (channel_sum(dy) if want_db else None)
+    dw = r.permute(1, 0, 2, 3).flip(2, 3)
+    db = channel_sum(dy) if want_db else None
+    if out is None:
+        return dw.contiguous(), db
+    out[0].copy_(dw)
+    if want_db:
+        out[1].copy_(db)
+    return out[0], (out[1] if want_db else None)
 
 
-def conv_wgrad_raw(x, dy, cout, k, want_db, x_gelu=False):
+def conv_wgrad_raw(x, dy, cout, k, want_db, x_gelu=False, out=None):
     B, cin, H, W = x.shape
     ws = torch.empty(L.lib().nq_conv_wgrad_ws_floats(B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
-    dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32)
-    db = torch.empty(cout, device=x.device, dtype=torch.float32) if want_db else None
+    dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32) if out is None else out[0]
+    db = (torch.empty(cout, device=x.device, dtype=torch.float32) if out is None else out[1]) if want_db else None
     _timed(("conv_wgrad", k, cin, cout, H, W, B, 0),
            lambda: L.check(L.lib().nq_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k,
                                                  1 if x_gelu else 0, _stream()), "conv_wgrad"))
@@ -641,6 +648,18 @@ def _channels_from_space(g, fh, fw):
     return g.view(n, c, hh // fh, fh, ww // fw, fw).permute(0, 1, 3, 5, 2, 4).reshape(n, c * fh * fw, hh // fh, ww // fw)
 
 
+# Data-parallel hook: when set, the decoder node writes ALL conv weight/bias gradients into one flat arena
+# and calls the hook on it once, at the end of its backward (e.g. an in-place RCCL all-reduce with ReduceOp.AVG): no
+# flatten / un-flatten copies around the collective.  model_reconstruction installs it when torch.distributed is up.
+_GRAD_ARENA_HOOK = None
+GRAD_ARENA_REDUCED = False   # set by the node when the hook ran (the caller then skips its own exchange)
+
+
+def set_grad_arena_hook(fn):
+    global _GRAD_ARENA_HOOK
+    _GRAD_ARENA_HOOK = fn
+
+
 _SIDE_STREAMS = {}
 
 
@@ -744,16 +763,34 @@ class _DecoderStackFn(Function):
         side = _side_stream(g.device) if spec.overlap_wgrad else None
         keep = []
 
+        # one flat arena for all weight/bias gradients when a data-parallel hook is installed (in-place collective)
+        arena = views = None
+        if _GRAD_ARENA_HOOK is not None:
+            sizes = []
+            for l in range(n):
+                k, r, act, cout, cin = metas[l][:5]
+                sizes += [cout * cin * k * k, cout if metas[l][8] else 0]
+            arena = torch.empty(sum(sizes), device=g.device, dtype=torch.float32)
+            views, off = [], 0
+            for l in range(n):
+                k, r, act, cout, cin = metas[l][:5]
+                wv = arena[off:off + sizes[2 * l]].view(cout, cin, k, k)
+                off += sizes[2 * l]
+                bv = arena[off:off + sizes[2 * l + 1]] if sizes[2 * l + 1] else None
+                off += sizes[2 * l + 1]
+                views.append((wv, bv))
+
         def wgrad(l, dconv):
             k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
             x_in = xs[l]
             Bx, _, Hx, Wx = x_in.shape
+            out = views[l] if views is not None else None
             if spec.precision == "bf16x3" and not in_gelu and conv_wgrad3_supported(Bx, cin, Hx, Wx, cout, k):
-                return conv_wgrad3_raw(x_in, dconv, cout, k, has_b)
+                return conv_wgrad3_raw(x_in, dconv, cout, k, has_b, out=out)
             if spec.precision == "bf16x3" and not in_gelu and cout <= 4 and cin > 4 and cout * k * k <= 64 \
                     and conv_wgrad3_supported(Bx, cout, Hx, Wx, cin, k):
-                return conv_wgrad_swapped3(x_in, dconv, cout, k, has_b)
-            return conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu)
+                return conv_wgrad_swapped3(x_in, dconv, cout, k, has_b, out=out)
+            return conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu, out=out)
 
         for l in range(n - 1, -1, -1):
             k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
@@ -785,6 +822,10 @@ class _DecoderStackFn(Function):
         if side is not None:
             main.wait_stream(side)
             keep.clear()
+        global GRAD_ARENA_REDUCED
+        if arena is not None:
+            _GRAD_ARENA_HOOK(arena)
+            GRAD_ARENA_REDUCED = True
         return (None, None) + tuple(grads)
 
 

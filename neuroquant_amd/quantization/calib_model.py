@@ -154,6 +154,11 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
     dp = torch.distributed.is_available() and torch.distributed.is_initialized() and \
         (torch.distributed.get_world_size() > 1 or bool(os.environ.get("NQ_DP_REHEARSAL")))
 
+    if dp and device.type == 'cuda':
+        # fused decoder node: gradients land in one arena that is all-reduced in place (RCCL, mean over ranks)
+        import torch.distributed as dist
+        ops.set_grad_arena_hook(lambda arena: dist.all_reduce(arena, op=dist.ReduceOp.AVG))
+
     def run(epochs, params, opt_lr, max_count, ada):
         nonlocal done
         opt = ops.FusedAdam(params, lr=opt_lr)
@@ -182,10 +187,12 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                 else:
                     for L in layers:
                         L.forward_uaq()
+                ops.GRAD_ARENA_REDUCED = False
                 img_out, _, _ = model(inputs)
                 rec, dimg = ops.l2_loss_and_grad(img_out, img)   # lp_loss p=2 (quantizer.py:66-71) and its gradient
                 img_out.backward(dimg)
-                if dp:  # data-parallel: one all-reduce over the raw conv weight+bias gradients
+                if dp and not ops.GRAD_ARENA_REDUCED:
+                    # generic path (decoder not fused into one node): flatten, all-reduce, un-flatten
                     allreduce_mean_([t.grad for L in layers for t in (L.W, L.b)])
                 grads = []
                 if ada:   # d(alpha) of all 14 tensors (+ regulariser gradient on the weights) in one launch
@@ -241,6 +248,8 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
         params += [m.weight_quantizer.alpha, m.bias_quantizer.alpha]
     run(int(iters / len(gt)) - epochs1, params, lr, iters, ada=True)
     torch.cuda.empty_cache()
+
+    ops.set_grad_arena_hook(None)
 
     # ---- finish: weights go hard; the bias quantisers stay soft, as in the reference (calib_model.py:231-240) ----
     for L in layers:

@@ -744,3 +744,39 @@ def test_multi_tensor_kernels_equal_single_tensor_ones(ops):
             ops.adam_step(p, gr, m, v, 0.003, t)
     for a, b in zip(ps, ref):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("arch,had", [("hnerv", False), ("nerv", True)])
+def test_gradient_arena_hook_is_transparent(ops, golden, arch, had):
+    """Data-parallel plumbing on one GPU: with a gradient-arena hook installed (what model_reconstruction does when
+    torch.distributed is up) all conv weight/bias gradients are written into ONE flat buffer that the hook sees once per
+    backward; with an identity hook the calibration is bit-identical to the run without it, and a hook that scales the
+    arena scales every gradient (i.e. the parameter side really consumes the arena)."""
+    from neuroquant_amd.models import _decode
+    from neuroquant_amd.quantization import QuantModel
+    z = golden("decode.npz")
+    sd = state_dict_from_npz(z, f"{arch}_sd:")
+    emb = G(z[f"{arch}_emb"])
+
+    def grads(hook):
+        qnn = QuantModel(_build(arch, sd), hadamard=had, weight_quant_params=dict(n_bits=8, channel_wise=True))
+        spec, provs = _decode._fused_stack(qnn.model)
+        g = torch.Generator().manual_seed(4)
+        ws = [tuple(t.detach().clone().requires_grad_(True) for t in p()) for p in provs]
+        ops.set_grad_arena_hook(hook)
+        try:
+            out = ops.decoder_stack(emb, spec, ws)
+            (out * torch.randn(out.shape, generator=g).to(DEV)).sum().backward()
+        finally:
+            ops.set_grad_arena_hook(None)
+        return [t.grad.clone() for pair in ws for t in pair]
+
+    seen = []
+    base = grads(None)
+    same = grads(lambda arena: seen.append(arena.numel()))
+    assert seen == [sum(t.numel() for t in base)]
+    for a, b in zip(base, same):
+        assert torch.equal(a, b)
+    half = grads(lambda arena: arena.mul_(0.5))
+    for a, b in zip(base, half):
+        assert torch.equal(a * 0.5, b)
