@@ -170,6 +170,7 @@ CONV_CASES = [
     (1, 53, 8, 33, 176, 5, "psgelu", 2),      # dec4 channel geometry
     (1, 160, 1, 1, 1160, 1, "plain", 1),      # NeRV stem
     (1, 20, 5, 70, 200, 3, "plain", 1),       # > 176 output channels -> several channel tiles
+    (2, 14, 6, 10, 72, 5, "psgelu", 3),       # r=3 block (UVG strides 5,4,4,3,2)
 ]
 
 
@@ -204,7 +205,9 @@ def test_conv_forward_backward(ops, case):
 @pytest.mark.parametrize("case", [(2, 44, 24, 96, 148, 5, "psgelu", 2), (2, 148, 24, 96, 44, 5, "plain", 1),
                                   (3, 53, 17, 70, 176, 5, "psgelu", 2), (2, 64, 40, 80, 848, 5, "psgelu", 4),
                                   (2, 20, 33, 100, 96, 3, "tanh", 1), (4, 9, 16, 64, 36, 3, "dgrad", 2),
-                                  (2, 848, 40, 80, 64, 5, "dgrad", 4), (1, 200, 20, 40, 64, 5, "plain", 1)])
+                                  (2, 848, 40, 80, 64, 5, "dgrad", 4), (1, 200, 20, 40, 64, 5, "plain", 1),
+                                  (2, 64, 48, 96, 144, 5, "psgelu", 3), (2, 40, 48, 96, 16, 5, "dgrad", 3),
+                                  (2, 30, 120, 240, 40, 5, "dgrad", 3)])
 def test_conv_bf16x3(ops, case):
     """bf16x3 kernel (split operands on the BF16 matrix pipe) vs float64: error stays at the fp32 level (a few 1e-6
     relative to the output scale), forward epilogues and the data-gradient operand (transposed=True) included.  Grids
