@@ -234,15 +234,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nb], acc[mi][nb], 0, 0, 0);
           acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nb], acc[mi][nb], 0, 0, 0);
         }
-      });
-      if (g + 1 < G) {  // publish step g+1 (loaded one step ago) into the other LDS buffer
-        u32x4* wdst = wl0 + (gp ^ 1) * W_U4;
-        if constexpr (gp == 0) {
-          NQ3_STORE_W(wvB, wdst)
-        } else {
-          NQ3_STORE_W(wvA, wdst)
+        if constexpr (mi == (MI - 1) / 2) {
+          // publish step g+1 (loaded one step ago) into the other LDS buffer -- in the MIDDLE of the MFMA block, so the
+          // LDS write latency is covered by the remaining MFMAs instead of sitting in front of the barrier (that buffer
+          // was last read in step g-1, which every wave left through the previous barrier)
+          if (g + 1 < G) {
+            u32x4* wdst = wl0 + (gp ^ 1) * W_U4;
+            if constexpr (gp == 0) {
+              NQ3_STORE_W(wvB, wdst)
+            } else {
+              NQ3_STORE_W(wvA, wdst)
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-      }
+      });
       if constexpr (st == NST - 1) {
         if (ch + 1 < nchunk) {
           __syncthreads();  // every wave is done with the current patch
