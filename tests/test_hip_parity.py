@@ -134,7 +134,9 @@ def test_adam_kernel(ops):
 
 
 # ------------------------------------------------------------------------------------------ Hadamard
-@pytest.mark.parametrize("shape", ((6, 16, 3, 3), (5, 64, 1, 1), (3, 128, 5, 5), (2, 256, 3, 3), (4, 1, 1, 1), (2, 1024, 1, 1)))
+@pytest.mark.parametrize("shape", ((6, 16, 3, 3), (5, 64, 1, 1), (3, 128, 5, 5), (2, 256, 3, 3), (4, 1, 1, 1), (2, 1024, 1, 1),
+                                   (37, 256, 3, 3),      # ragged last workgroup (37 rows, 3 per workgroup)
+                                   (3, 512, 5, 5)))      # row longer than the LDS tile -> column-gather fallback
 def test_fwht(ops, shape):
     g = torch.Generator().manual_seed(1)
     w = torch.randn(shape, generator=g)
