@@ -154,12 +154,36 @@ def sensitivity_criterion(mode, arch, net, qnn, dataloader, use_cuda=True):
     raise ValueError('Not implemented sensitivity criteria: {}'.format(mode))
 
 
+def owned_candidates(names, rank=0, world=1):
+    """Candidates scored by `rank`: round-robin in dict order (candidates are independent -> replicas, no collective
+    on the data path)."""
+    return [n for i, n in enumerate(names) if i % world == rank]
+
+
+def gather_scores(scores, world):
+    """Union of the per-rank {name: score} dicts on every rank (torch.distributed.all_gather_object)."""
+    if world <= 1:
+        return dict(scores)
+    import torch.distributed as dist
+    gathered = [None] * world
+    dist.all_gather_object(gathered, scores)
+    return {k: v for d in gathered for k, v in d.items()}
+
+
+def pick_best(candidate_dict, scores):
+    """Lowest score wins; ties go to the earlier candidate (bit_assign.py:361-365 uses a strict '<')."""
+    names = list(candidate_dict)
+    best = min(names, key=lambda c: (scores[c], names.index(c)))
+    return best, candidate_dict[best], scores[best]
+
+
 def score_candidates(model, candidate_dict, cali_data, cache, args, rank=0, world=1):
-    """-> {name: score} for the candidates this rank owns (name order, round-robin over ranks)."""
+    """-> {name: score} for the candidates this rank owns."""
     device = next(model.parameters()).device
     scores = {}
-    for ci, (candidate, bits) in enumerate(candidate_dict.items()):
-        if ci % world != rank:
+    mine = set(owned_candidates(list(candidate_dict), rank, world))
+    for candidate, bits in candidate_dict.items():
+        if candidate not in mine:
             continue
         wq_params = {'n_bits': 8, 'channel_wise': args.channel_wise, 'scale_method': args.init}
         qnn = QuantModel(model=copy.deepcopy(model), hadamard=args.hadamard, weight_quant_params=wq_params).to(device)
@@ -208,14 +232,8 @@ def assign(args, cfg):
         candidate_dict = {f'candidate{i + 1}': [int(b) for b in c.split()] for i, c in enumerate(args.candidates)}
     else:
         candidate_dict = hnerv_candidate if args.arch == 'hnerv' else nerv_candidate
-    scores = score_candidates(model, candidate_dict, cali_data, cache, args, rank, world)
-    if world > 1:   # candidates are independent: gather the per-rank scores (no data-path collective)
-        gathered = [None] * world
-        dist.all_gather_object(gathered, scores)
-        scores = {k: v for d in gathered for k, v in d.items()}
-
-    best_candidate = min(candidate_dict, key=lambda c: (scores[c], list(candidate_dict).index(c)))
-    best_bits, best_score = candidate_dict[best_candidate], scores[best_candidate]
+    scores = gather_scores(score_candidates(model, candidate_dict, cali_data, cache, args, rank, world), world)
+    best_candidate, best_bits, best_score = pick_best(candidate_dict, scores)
     logging.info("=" * 60)
     logging.info(f"Best Candidate: {best_candidate}")
     logging.info(f"Bit Configuration: {best_bits}")

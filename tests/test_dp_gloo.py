@@ -72,6 +72,18 @@ def _worker(rank, world, port, out):
         gl = [gw_local.clone()]
         allreduce_mean_(gl)
         assert torch.allclose(gl[0], gw_global, rtol=1e-6)
+        # bit-allocation sweep: candidates are dealt round-robin to the ranks, scores gathered everywhere
+        from neuroquant_amd.methods import bit_assign as ba
+        cands = {f"candidate{i + 1}": [2 + (i + j) % 6 for j in range(7)] for i in range(5)}
+        mine = ba.owned_candidates(list(cands), rank, world)
+        assert mine == [n for i, n in enumerate(cands) if i % world == rank]
+        scores = ba.gather_scores({n: float(sum(cands[n])) + 0.25 * rank for n in mine}, world)
+        assert set(scores) == set(cands)
+        best, bits, sc = ba.pick_best(cands, scores)
+        assert sc == min(scores.values()) and bits == cands[best]
+        picks = [None] * world
+        dist.all_gather_object(picks, best)
+        assert len(set(picks)) == 1                                 # every rank reports the same winner
         out.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         out.put((rank, repr(e)))
@@ -96,3 +108,16 @@ def test_allreduce_is_noop_without_process_group():
     from neuroquant_amd.utils import allreduce_mean_
     t = [torch.ones(3)]
     assert allreduce_mean_(t)[0].equal(torch.ones(3))
+
+
+def test_full_loader_covers_every_frame_once_without_dropping():
+    """bit_assign's FullLoader = the reference's full_dataloader (shuffle=True, drop_last=False)."""
+    from neuroquant_amd.methods.bit_assign import FullLoader, owned_candidates, pick_best
+    ld = FullLoader(_FakeCache(11), batch_size=4, seed=903)
+    assert len(ld) == 3
+    idx = torch.cat([b["idx"] for b in ld])
+    assert sorted(idx.tolist()) == list(range(11))
+    sizes = [b["idx"].numel() for b in FullLoader(_FakeCache(11), 4)]
+    assert sizes == [4, 4, 3]
+    assert owned_candidates(["a", "b", "c"], 0, 1) == ["a", "b", "c"]
+    assert pick_best({"a": [2], "b": [3]}, {"a": 1.0, "b": 1.0})[0] == "a"      # ties go to the earlier candidate
