@@ -228,12 +228,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           ah0 = __builtin_bit_cast(bf16x8, wb[(mi + 1) * 16]);
           al0 = __builtin_bit_cast(bf16x8, wb[4 * MT + (mi + 1) * 16]);
         }
+        // product-major order: the three MFMAs that accumulate into one register are 4 issues apart (a dependent MFMA
+        // issued back to back waits for its predecessor's result: the compiler otherwise chains them through a temporary)
 #pragma unroll
-        for (int nb = 0; nb < 4; ++nb) {
-          acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nb], acc[mi][nb], 0, 0, 0);
-          acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nb], acc[mi][nb], 0, 0, 0);
-          acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nb], acc[mi][nb], 0, 0, 0);
-        }
+        for (int nb = 0; nb < 4; ++nb) acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nb], acc[mi][nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nb], acc[mi][nb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nb], acc[mi][nb], 0, 0, 0);
         if constexpr (mi == (MI - 1) / 2) {
           // publish step g+1 (loaded one step ago) into the other LDS buffer -- in the MIDDLE of the MFMA block, so the
           // LDS write latency is covered by the remaining MFMAs instead of sitting in front of the barrier (that buffer
