@@ -269,10 +269,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int cur = (seg - seg_lo) & 1;
     const u32x4* __restrict__ dz = reinterpret_cast<const u32x4*>(smem + cur * BUF_BYTES) + a_lane;
     const unsigned* __restrict__ xw = reinterpret_cast<const unsigned*>(smem + cur * BUF_BYTES + DZ_U4 * 16);
-    // B fragments: 8 words per n-block -> hi / lo vectors
-    bf16x8 bh[NI], bl[NI];
+    // A fragments (dY) of all channel blocks stay in registers (2 x 4 x MI VGPRs); B fragments (x) are built one n-block
+    // at a time, just before their MFMAs, and the next one is assembled while the current block's MFMAs run: fewer
+    // live registers than holding all NI B fragments (the 5x6 tile no longer spills) and the MFMAs that accumulate into
+    // one register are MI issues apart (product-major order).
+    bf16x8 ah[MI], al[MI];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
+    for (int mi = 0; mi < MI; ++mi) {
+      ah[mi] = __builtin_bit_cast(bf16x8, dz[mi * 16]);
+      al[mi] = __builtin_bit_cast(bf16x8, dz[4 * MT + mi * 16]);
+    }
+    auto build_B = [&](int ni, bf16x8& h, bf16x8& l) {
       unsigned w[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) w[j] = xw[lc[ni] + j];
@@ -282,35 +289,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         hi[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x07060302u);  // {hi16(w0), hi16(w1) << 16}
         lo[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x05040100u);  // {lo16(w0), lo16(w1) << 16}
       }
-      bh[ni] = __builtin_bit_cast(bf16x8, hi);
-      bl[ni] = __builtin_bit_cast(bf16x8, lo);
-    }
-    bf16x8 ah0 = __builtin_bit_cast(bf16x8, dz[0]), al0 = __builtin_bit_cast(bf16x8, dz[4 * MT]);
-    wg3_steps<0, MI>([&](auto mi_c) {
-      constexpr int mi = decltype(mi_c)::value;
-      bf16x8 ah = ah0, al = al0;
-      if constexpr (mi + 1 < MI) {
-        ah0 = __builtin_bit_cast(bf16x8, dz[(mi + 1) * 16]);
-        al0 = __builtin_bit_cast(bf16x8, dz[4 * MT + (mi + 1) * 16]);
-      }
-      if constexpr (MI * NI < 30) {
-        // product-major order: MFMAs accumulating into one register are NI issues apart (a dependent MFMA issued back
-        // to back waits for its predecessor's result)
+      h = __builtin_bit_cast(bf16x8, hi);
+      l = __builtin_bit_cast(bf16x8, lo);
+    };
+    bf16x8 bh0, bl0;
+    build_B(0, bh0, bl0);
+    wg3_steps<0, NI>([&](auto ni_c) {
+      constexpr int ni = decltype(ni_c)::value;
+      const bf16x8 bh = bh0, bl = bl0;
+      if constexpr (ni + 1 < NI) build_B(ni + 1, bh0, bl0);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
+      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
+      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ni], acc[mi][ni], 0, 0, 0);
-      } else {
-        // the 5 x 6 tile sits at the 256-VGPR limit: this order keeps the register allocator from spilling more
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[ni], acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[ni], acc[mi][ni], 0, 0, 0);
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[ni], acc[mi][ni], 0, 0, 0);
-        }
-      }
+      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
     });
     if (seg + 1 < seg_hi) store_seg(smem + (cur ^ 1) * BUF_BYTES);
     __syncthreads();
