@@ -125,7 +125,20 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
   Wg3Plan p;
   p.mi = pick_mi3(Cout);
   const int N = Cin * k * k;
-  p.ni = (N <= 64) ? 1 : 6;
+  if (N <= 64) {
+    p.ni = 1;
+  } else {   // n-tile of 64*ni columns: the ni in {5,6,7} that pads C_in*k*k least (7 only with <= 4 channel blocks);
+             // ties go to the wider tile (fewer tiles re-staging dY)
+    int best = 6, best_pad = 1 << 30;
+    for (int ni = 5; ni <= (p.mi <= 4 ? 7 : 6); ++ni) {
+      const int nt = 64 * ni, pad = (N + nt - 1) / nt * nt;
+      if (pad <= best_pad) {
+        best_pad = pad;
+        best = ni;
+      }
+    }
+    p.ni = best;
+  }
   const int mt = 16 * p.mi, nt = 64 * p.ni;
   p.co_pad = (Cout + mt - 1) / mt * mt;
   p.n_pad = (N + nt - 1) / nt * nt;

@@ -361,7 +361,8 @@ int launch_wgrad3(const Wgrad3Args& a, hipStream_t st) {
 #define NQ_CAT2(a, b) a##b
 #define NQ_CAT(a, b) NQ_CAT2(a, b)
 
-// tile: MT = 16*mi_sel channels (mi_sel in 1..5), NT = 64*ni_sel n-values (ni_sel = 6, or 1 for C_in*k*k <= 64)
+// tile: MT = 16*mi_sel channels (mi_sel in 1..5), NT = 64*ni_sel n-values (ni_sel in {5,6,7}: least padding of C_in*k*k,
+// or 1 for C_in*k*k <= 64)
 extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, float* slab, float* slab_db, int B, int Cin,
                                                 int H, int W, int Cout, int co_pad, int n_pad, int nsplit, int mi_sel,
                                                 int ni_sel, hipStream_t st) {
@@ -382,12 +383,27 @@ extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, 
       default: return NQ_ERR_UNSUPPORTED;
     }
   }
-  switch (mi_sel) {
-    case 1: return launch_wgrad3<1, 6>(a, st);
-    case 2: return launch_wgrad3<2, 6>(a, st);
-    case 3: return launch_wgrad3<3, 6>(a, st);
-    case 4: return launch_wgrad3<4, 6>(a, st);
-    case 5: return launch_wgrad3<5, 6>(a, st);
-    default: return NQ_ERR_UNSUPPORTED;
+#define NQ_WG3_CASES(NI_)                                  \
+  switch (mi_sel) {                                        \
+    case 1: return launch_wgrad3<1, NI_>(a, st);           \
+    case 2: return launch_wgrad3<2, NI_>(a, st);           \
+    case 3: return launch_wgrad3<3, NI_>(a, st);           \
+    case 4: return launch_wgrad3<4, NI_>(a, st);           \
+    case 5: return launch_wgrad3<5, NI_>(a, st);           \
+    default: return NQ_ERR_UNSUPPORTED;                    \
   }
+  if (ni_sel == 5) {
+    NQ_WG3_CASES(5)
+  }
+  if (ni_sel == 7) {   // 7 n-blocks only with <= 4 channel blocks (accumulators: 16*MI*NI/... = 112 VGPRs at 4x7)
+    switch (mi_sel) {
+      case 1: return launch_wgrad3<1, 7>(a, st);
+      case 2: return launch_wgrad3<2, 7>(a, st);
+      case 3: return launch_wgrad3<3, 7>(a, st);
+      case 4: return launch_wgrad3<4, 7>(a, st);
+      default: return NQ_ERR_UNSUPPORTED;
+    }
+  }
+  NQ_WG3_CASES(6)
+#undef NQ_WG3_CASES
 }
