@@ -120,8 +120,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ data gradient
-template <int KS>
-__global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wt, int ld,
+// R2 = 1: r == 2 with W % 4 == 0 and H % 2 == 0 checked by the host -> only the 8-byte un-shuffle stores are compiled
+// (the generic path's 64-bit per-element addressing otherwise sets the kernel's VGPR count and halves the occupancy).
+template <int KS, int R2, int NCO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS <= 3 && NCO <= 3 && R2) ? 4 : 1, 8))) void head_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wt, int ld,
                                                          const float* __restrict__ zprev, float* __restrict__ out,
                                                          int Cin, int H, int W, int CO, int r, int tiles_x) {
   // NB naming follows the data-gradient use: "CO" (<= 4) = channels of the INPUT dy, "Cin" = channels of the OUTPUT;
@@ -130,11 +132,12 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
   constexpr int TH = 16, TW = 64;
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
   constexpr int PWS = (PW + 3) / 4 * 4;
-  __shared__ __attribute__((aligned(16))) float patch[MAXCO * PH * PWS];
+  __shared__ __attribute__((aligned(16))) float patch[NCO * PH * PWS];
   // weights of one output channel ci, contiguous: wl[ci][co*KK + tap] (row padded to a multiple of 4 floats).  The
-  // operand arrives k-major ([co*KK + tap][ld]): reading it per ci would be MAXCO*KK separate scalar loads; from LDS it is
-  // MAXCO*KK/4 broadcast ds_read_b128.
-  constexpr int WROW = (MAXCO * KK + 3) / 4 * 4;
+  // operand arrives k-major ([co*KK + tap][ld]): reading it per ci would be NCO*KK separate scalar loads; from LDS it is
+  // NCO*KK/4 broadcast ds_read_b128.
+  constexpr int KKP = (KK + 3) / 4 * 4;        // taps of one input channel, padded to whole 16-byte vectors
+  constexpr int WROW = NCO * KKP;
   constexpr int WL_MAX = 64;   // output channels cached per pass (64 * 112 * 4 B = 28 KB for k = 5)
   __shared__ __attribute__((aligned(16))) float wl[WL_MAX * WROW];
 
@@ -155,9 +158,9 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
   }
   __syncthreads();
   // the thread's dY neighbourhood: CO x KS rows x (4+KS-1) columns, kept in registers for the whole C_in loop
-  float nb[MAXCO][KS][4 + KS - 1];
+  float nb[NCO][KS][4 + KS - 1];
 #pragma unroll
-  for (int co = 0; co < MAXCO; ++co)
+  for (int co = 0; co < NCO; ++co)
 #pragma unroll
     for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
@@ -166,13 +169,15 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
   const int gy = y0 + row, gx0 = x0 + c4;
   const bool active = (gy < H && gx0 < W);   // inactive threads still help staging the weights and join the barriers
   const bool full = (gx0 + 3 < W);
+#pragma unroll 1
   for (int ci = 0; ci < Cin; ++ci) {
     if (ci % WL_MAX == 0) {   // (re)fill the weight cache for output channels [ci, ci + WL_MAX)
       __syncthreads();
       const int nci = min(WL_MAX, Cin - ci);
       for (int e = tid; e < nci * WROW; e += 256) {
-        const int cl = e / WROW, j = e - cl * WROW;   // j = co*KK + tap
-        wl[e] = (j < CO * KK) ? wt[(int64_t)j * ld + ci + cl] : 0.f;
+        const int cl = e / WROW, j = e - cl * WROW;
+        const int co = j / KKP, tap = j - co * KKP;
+        wl[e] = (co < CO && tap < KK) ? wt[(int64_t)(co * KK + tap) * ld + ci + cl] : 0.f;
       }
       __syncthreads();
     }
@@ -180,16 +185,24 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     const float* __restrict__ wrow = wl + (ci % WL_MAX) * WROW;
 #pragma unroll
-    for (int co = 0; co < MAXCO; ++co) {
+    for (int co = 0; co < NCO; ++co) {
       if (co < CO) {
+        // the KK weights of (ci, co): KKP/4 broadcast 16-byte LDS reads (same address in every lane), consumed before the
+        // next input channel's are requested -- keeps ~28 weight registers live instead of all NCO*KK
+        float wv[KKP];
+#pragma unroll
+        for (int q = 0; q < KKP / 4; ++q) {
+          const float4 t = *reinterpret_cast<const float4*>(wrow + co * KKP + 4 * q);
+          wv[4 * q] = t.x; wv[4 * q + 1] = t.y; wv[4 * q + 2] = t.z; wv[4 * q + 3] = t.w;
+        }
 #pragma unroll
         for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
           for (int kw = 0; kw < KS; ++kw) {
-            const float wv = wrow[co * KK + kh * KS + kw];  // same address in every lane: LDS broadcast
 #pragma unroll
-            for (int p = 0; p < 4; ++p) acc[p] = fmaf(wv, nb[co][kh][p + kw], acc[p]);
+            for (int p = 0; p < 4; ++p) acc[p] = fmaf(wv[kh * KS + kw], nb[co][kh][p + kw], acc[p]);
           }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     const int64_t zi = ((int64_t)b * Cin + ci) * HW + (int64_t)gy * W + gx0;
@@ -203,7 +216,12 @@ __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict
           if (gx0 + p < W) acc[p] *= zprev[zi + p];
       }
     }
-    if (r == 1) {
+    if constexpr (R2) {
+      const int Ho = H >> 1, Wo = W >> 1;
+      const int64_t base = ((((int64_t)b * Cin + ci) * 4 + (gy & 1) * 2) * Ho + (gy >> 1)) * (int64_t)Wo + (gx0 >> 1);
+      *reinterpret_cast<float2*>(out + base) = make_float2(acc[0], acc[2]);
+      *reinterpret_cast<float2*>(out + base + (int64_t)Ho * Wo) = make_float2(acc[1], acc[3]);
+    } else if (r == 1) {
 #pragma unroll
       for (int p = 0; p < 4; ++p)
         if (gx0 + p < W) out[zi + p] = acc[p];
@@ -252,11 +270,20 @@ int nq_head_dgrad(const float* dy, const float* wt, int ld, const float* zprev, 
                   int Cout, int k, int r, hipStream_t st) {
   const int tiles_x = (W + 63) / 64, tiles = tiles_x * ((H + 15) / 16);
   dim3 g((unsigned)tiles, (unsigned)B), blk(256);
+  const bool r2 = (r == 2) && (W % 4 == 0) && (H % 2 == 0);
+#define NQ_HD(KS_, R2_) \
+  do {                                                                                                              \
+    if (Cout <= 3)                                                                                                  \
+      hipLaunchKernelGGL((head_dgrad_kernel<KS_, R2_, 3>), g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, tiles_x); \
+    else                                                                                                            \
+      hipLaunchKernelGGL((head_dgrad_kernel<KS_, R2_, 4>), g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, tiles_x); \
+  } while (0)
   switch (k) {
-    case 1: hipLaunchKernelGGL(head_dgrad_kernel<1>, g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, tiles_x); break;
-    case 3: hipLaunchKernelGGL(head_dgrad_kernel<3>, g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, tiles_x); break;
-    default: hipLaunchKernelGGL(head_dgrad_kernel<5>, g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, tiles_x); break;
+    case 1: if (r2) NQ_HD(1, 1); else NQ_HD(1, 0); break;
+    case 3: if (r2) NQ_HD(3, 1); else NQ_HD(3, 0); break;
+    default: if (r2) NQ_HD(5, 1); else NQ_HD(5, 0); break;
   }
+#undef NQ_HD
   return nq_launch_status();
 }
 
