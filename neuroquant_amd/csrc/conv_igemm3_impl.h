@@ -34,6 +34,7 @@
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef f32x4 f32x4_u __attribute__((aligned(4)));
 using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
@@ -110,36 +111,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // ---- staging state: weights are prefetched TWO k-steps ahead (two register sets; an L2 round trip under load is
   //      ~2-3 k-steps of MFMA time), the next chunk's patch three steps before it is needed ----
-  float pv[IPT][8];
+  // Patch staging item = (channel octet, patch row, 4-pixel quad): ONE 16-byte global load per channel (8 per thread
+  // and chunk instead of 32 scalar ones -- global memory instructions cost ~150 cycles of CU time each, whatever their
+  // width), split into bf16 hi/lo per pixel afterwards.  2 * PH * QP items <= 256: one item per thread.
+  constexpr int QP = (PW + 3) / 4;
+  static_assert(2 * PH * QP <= 256, "one staging item per thread");
+  const int it_oct = tid / (PH * QP), it_rem = tid - it_oct * (PH * QP);
+  const int it_r = it_rem / QP, it_q = it_rem - it_r * QP;
+  const int it_gy = y0 - PAD + it_r, it_gx = x0 - PAD + 4 * it_q;
+  const bool it_row = (tid < 2 * PH * QP) && it_gy >= 0 && it_gy < H;
+  const bool it_in = it_gx >= 0 && it_gx + 3 < W;                 // the whole quad is inside the image
+  const int64_t it_off = (int64_t)it_gy * W + it_gx;
+  f32x4 pv[8];
   u32x4 wvA[WPT], wvB[WPT];
 #define NQ3_LOAD_PATCH(CH)                                                                            \
   {                                                                                                   \
-    int t_ = tid;                                                                                     \
-    asm volatile("" : "+v"(t_));                                                                      \
-    _Pragma("unroll") for (int i = 0; i < IPT; ++i) {                                                 \
-      const int e_ = t_ + i * 256;                                                                    \
-      const int oct_ = e_ / NPIX, pix_ = e_ - oct_ * NPIX;                                            \
-      const int py_ = pix_ / PW, px_ = pix_ - py_ * PW;                                               \
-      const int gy_ = y0 - PAD + py_, gx_ = x0 - PAD + px_;                                           \
-      const bool ok_ = (e_ < NITEM) && gy_ >= 0 && gy_ < H && gx_ >= 0 && gx_ < W;                    \
-      const int ch0_ = (CH) * CC + oct_ * 8;                                                          \
-      const float* p_ = xb + (int64_t)ch0_ * HW + (int64_t)gy_ * W + gx_;                             \
-      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                                   \
-          pv[i][j] = (ok_ && ch0_ + j < Cin) ? p_[(int64_t)j * HW] : 0.f;                             \
+    const int ch0_ = (CH) * CC + it_oct * 8;                                                          \
+    const float* p_ = xb + (int64_t)ch0_ * HW + it_off;                                               \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
+      f32x4 v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                                           \
+      if (it_row && ch0_ + j < Cin) {                                                                 \
+        const float* q_ = p_ + (int64_t)j * HW;                                                       \
+        if (it_in) {                                                                                  \
+          v_ = *reinterpret_cast<const f32x4_u*>(q_);                                                 \
+        } else {                                                                                      \
+          _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                            \
+              if (it_gx + e_ >= 0 && it_gx + e_ < W) v_[e_] = q_[e_];                                 \
+        }                                                                                             \
+      }                                                                                               \
+      pv[j] = v_;                                                                                     \
     }                                                                                                 \
   }
 #define NQ3_STORE_PATCH(DST)                                                                          \
-  {                                                                                                   \
-    int t_ = tid;                                                                                     \
-    asm volatile("" : "+v"(t_));                                                                      \
-    _Pragma("unroll") for (int i = 0; i < IPT; ++i) {                                                 \
-      const int e_ = t_ + i * 256;                                                                    \
-      if (e_ < NITEM) {                                                                               \
-        const int oct_ = e_ / NPIX, pix_ = e_ - oct_ * NPIX;                                          \
+  if (tid < 2 * PH * QP) {                                                                            \
+    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                \
+      if (4 * QP == PW || 4 * it_q + e_ < PW) {                                                       \
+        const float c_[8] = {pv[0][e_], pv[1][e_], pv[2][e_], pv[3][e_], pv[4][e_], pv[5][e_], pv[6][e_], pv[7][e_]}; \
         u32x4 hi_, lo_;                                                                               \
-        split8(pv[i], hi_, lo_);                                                                      \
-        (DST)[oct_ * PP + pix_] = hi_;                                                                \
-        (DST)[2 * PP + oct_ * PP + pix_] = lo_;                                                       \
+        split8(c_, hi_, lo_);                                                                         \
+        (DST)[it_oct * PP + it_r * PW + 4 * it_q + e_] = hi_;                                         \
+        (DST)[2 * PP + it_oct * PP + it_r * PW + 4 * it_q + e_] = lo_;                                \
       }                                                                                               \
     }                                                                                                 \
   }
