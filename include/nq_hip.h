@@ -209,7 +209,7 @@ int nq_l2_loss(const float* pred, const float* tgt, float* loss, float* dpred, f
                float gscale, nq_stream_t stream);
 
 /* Per-channel sums of an NCHW tensor, out[c] = sum_{b,h,w} x[b][c][h][w] (bias gradient of a convolution);
- * ws: >= 64*C floats.  Deterministic. */
+ * ws: >= 512*C floats.  Deterministic. */
 int nq_channel_sum(const float* x, float* out, float* ws, int B, int C, int64_t HW, nq_stream_t stream);
 
 /* Per-frame PSNR pieces (utils.py:148-151): sse[f] = sum over one frame of (out-gt)^2, frames of frame_len floats. */

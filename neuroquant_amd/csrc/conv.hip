@@ -5,6 +5,14 @@
 #include "nq_common.h"
 
 extern "C" {
+int nq_tiny_pw_supported(int B, int Cin, int H, int W, int Cout, int k);
+int nq_tiny_pw_forward(const float* x, const float* wt, const float* bias, float* y, float* z, const float* zprev, int B,
+                       int Cin, int H, int W, int Cout, int ld, int r, int epi, hipStream_t st);
+int nq_tiny_pw_wgrad(const float* x, const float* dy, float* dw, float* db, int B, int Cin, int H, int W, int Cout,
+                     hipStream_t st);
+}
+
+extern "C" {
 int nq_conv_igemm_k1(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int,
                      int, float*, int, const float*, hipStream_t);
 int nq_conv_igemm_k3(const float*, const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int,
@@ -206,6 +214,9 @@ int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y
   if (use_head_dgrad(Cin, k, epilogue, in_gelu, bias))
     return nq_head_dgrad(x, wt, ld, epilogue == NQ_EPI_DGRAD_GELU ? zprev : nullptr, y, B, Cout, H, W, Cin, k,
                          epilogue == NQ_EPI_DGRAD_GELU ? r : 1, st0);
+  // 1x1 convolutions over a handful of pixels (decoder stem / first block): compact thread-per-output kernel
+  if (!in_gelu && nq_tiny_pw_supported(B, Cin, H, W, Cout, k))
+    return nq_tiny_pw_forward(x, wt, bias, y, z, zprev, B, Cin, H, W, Cout, ld, r, epilogue, st0);
   const int mi = pick_mi_fwd(Cout);
   const int ns = pick_nsplit(B, Cin, H, W, Cout, k);
   if (ns > 1 && !ws) return NQ_ERR_INVALID;
@@ -231,6 +242,8 @@ int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* 
                   int k, int x_gelu, nq_stream_t stream) {
   if (!x || !dy || !dw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
   if (!ks_ok(k)) return NQ_ERR_UNSUPPORTED;
+  if (!x_gelu && nq_tiny_pw_supported(B, Cin, H, W, Cout, k))
+    return nq_tiny_pw_wgrad(x, dy, dw, db, B, Cin, H, W, Cout, nq_s(stream));
   WgradPlan p = plan_wgrad(B, Cin, H, W, Cout, k);
   float* slab = ws;
   float* slab_db = ws + (int64_t)p.nsplit * p.co_pad * p.n_pad;

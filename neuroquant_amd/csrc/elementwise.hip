@@ -84,7 +84,7 @@ __global__ __launch_bounds__(1024) void frame_sse_kernel(const float* __restrict
 }
 
 // per-channel sums of an NCHW tensor (bias gradient of a conv): stage 1 = (chunk, channel) partials, stage 2 = fixed order
-constexpr int CS_CHUNKS = 64;
+constexpr int CS_CHUNKS = 512;   // (chunk, channel) workgroups: 1536 for a 3-channel image, enough to fill the chip
 __global__ __launch_bounds__(TPB) void channel_sum_stage1(const float* __restrict__ x, float* __restrict__ ws, int B, int C,
                                                           int64_t HW) {
   __shared__ float red[16];
@@ -102,6 +102,7 @@ __global__ void channel_sum_stage2(const float* __restrict__ ws, float* __restri
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float s = 0.f;
+#pragma unroll 8
   for (int k = 0; k < CS_CHUNKS; ++k) s += ws[c * CS_CHUNKS + k];
   out[c] = s;
 }

@@ -437,7 +437,7 @@ def channel_sum(x):
     x = _dev(x)
     B, C = x.shape[0], x.shape[1]
     out = torch.empty(C, device=x.device, dtype=torch.float32)
-    ws = torch.empty(64 * C, device=x.device, dtype=torch.float32)
+    ws = torch.empty(512 * C, device=x.device, dtype=torch.float32)
     L.check(L.lib().nq_channel_sum(_p(x), _p(out), _p(ws), B, C, x.numel() // (B * C), _stream()), "channel_sum")
     return out
 
