@@ -374,14 +374,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 #if NQ_KS == 1
-// Sums the split-K slabs and applies bias + epilogue (one thread per conv output element, x fastest).
+// Sums the split-K slabs and applies bias + epilogue (x fastest).  SG = 1: one thread per conv output element.
+// SG = 8 (small outputs with many slabs, e.g. 31k outputs x 128 slabs): 8 threads share an output, thread g adds slabs
+// g, g+8, ... and the 8 partial sums are combined through LDS in index order -- still a fixed order, 8x the parallelism.
+template <int SG>
 __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(ConvArgs a) {
+  constexpr int OG = 256 / SG;
+  __shared__ float part[SG][OG];
   const int64_t HW = (int64_t)a.H * a.W;
   const int64_t total = (int64_t)a.B * a.Cout * HW;
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
+  const int o = threadIdx.x % OG, g = threadIdx.x / OG;
+  int64_t i = (int64_t)blockIdx.x * OG + o;
   float v = 0.f;
-  for (int s = 0; s < a.nsplit; ++s) v += a.slab[s * total + i];
+  if (i < total) {
+#pragma unroll 4
+    for (int s = g; s < a.nsplit; s += SG) v += a.slab[s * total + i];
+  }
+  if (SG > 1) {
+    part[g][o] = v;
+    __syncthreads();
+    if (g != 0) return;
+    v = part[0][o];
+#pragma unroll
+    for (int j = 1; j < SG; ++j) v += part[j][o];
+  }
+  if (i >= total) return;
   const int px = (int)(i % a.W);
   const int py = (int)((i / a.W) % a.H);
   const int co = (int)((i / HW) % a.Cout);
@@ -420,7 +437,10 @@ extern "C" int nq_conv_splitk_finish(const float* slab, const float* bias, float
   a.slab = const_cast<float*>(slab); a.bias = bias; a.y = y; a.z = z; a.zprev = zprev;
   a.B = B; a.H = H; a.W = W; a.Cout = Cout; a.r = r; a.epi = epi; a.nsplit = nsplit;
   int64_t total = (int64_t)B * Cout * H * W;
-  hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
+  if (total < 131072 && nsplit >= 16)
+    hipLaunchKernelGGL(conv_splitk_finish_kernel<8>, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(conv_splitk_finish_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a);
   return nq_launch_status();
 }
 #endif
