@@ -122,14 +122,16 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 // ------------------------------------------------------------------------------------------------ data gradient
 // R2 = 1: r == 2 with W % 4 == 0 and H % 2 == 0 checked by the host -> only the 8-byte un-shuffle stores are compiled
 // (the generic path's 64-bit per-element addressing otherwise sets the kernel's VGPR count and halves the occupancy).
-template <int KS, int R2, int NCO>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS <= 3 && NCO <= 3 && R2) ? 4 : 1, 8))) void head_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wt, int ld,
+template <int KS, int R2, int NCO, int PX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS <= 3 && NCO <= 3 && R2 && PX == 4) ? 4 : 1, 8))) void head_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ wt, int ld,
                                                          const float* __restrict__ zprev, float* __restrict__ out,
                                                          int Cin, int H, int W, int CO, int r, int tiles_x) {
   // NB naming follows the data-gradient use: "CO" (<= 4) = channels of the INPUT dy, "Cin" = channels of the OUTPUT;
   // wt[(co*KK + tap)*ld + ci] is the (already tap-flipped) wt_bwd operand of nq_weight_layouts.
   constexpr int KK = KS * KS, PAD = KS / 2;
-  constexpr int TH = 16, TW = 64;
+  // PX pixels per thread (4, or 8 for the r == 2 fast path: un-shuffled stores become 16 bytes, 2 loads + 2 stores per
+  // 8 pixels and channel instead of 2 + 4 -- the kernel is bound by the number of global memory instructions)
+  constexpr int TW = 64, TPR = TW / PX, TH = 256 / TPR;
   constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
   constexpr int PWS = (PW + 3) / 4 * 4;
   __shared__ __attribute__((aligned(16))) float patch[NCO * PH * PWS];
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS <= 3 &&
   __shared__ __attribute__((aligned(16))) float wl[WL_MAX * WROW];
 
   const int tid = threadIdx.x;
-  const int row = tid >> 4, c4 = (tid & 15) * 4;
+  const int row = tid / TPR, c4 = (tid % TPR) * PX;
   const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
   const int x0 = tile_x * TW, y0 = tile_y * TH, b = blockIdx.y;
   const int64_t HW = (int64_t)H * W;
@@ -158,17 +160,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS <= 3 &&
   }
   __syncthreads();
   // the thread's dY neighbourhood: CO x KS rows x (4+KS-1) columns, kept in registers for the whole C_in loop
-  float nb[NCO][KS][4 + KS - 1];
+  float nb[NCO][KS][PX + KS - 1];
 #pragma unroll
   for (int co = 0; co < NCO; ++co)
 #pragma unroll
     for (int kh = 0; kh < KS; ++kh)
 #pragma unroll
-      for (int j = 0; j < 4 + KS - 1; ++j) nb[co][kh][j] = (co < CO) ? patch[(co * PH + row + kh) * PWS + c4 + j] : 0.f;
+      for (int j = 0; j < PX + KS - 1; ++j) nb[co][kh][j] = (co < CO) ? patch[(co * PH + row + kh) * PWS + c4 + j] : 0.f;
 
   const int gy = y0 + row, gx0 = x0 + c4;
   const bool active = (gy < H && gx0 < W);   // inactive threads still help staging the weights and join the barriers
-  const bool full = (gx0 + 3 < W);
+  const bool full = (gx0 + PX - 1 < W);
 #pragma unroll 1
   for (int ci = 0; ci < Cin; ++ci) {
     if (ci % WL_MAX == 0) {   // (re)fill the weight cache for output channels [ci, ci + WL_MAX)
@@ -182,7 +184,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS <= 3 &&
       __syncthreads();
     }
     if (!active) continue;
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    float acc[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) acc[p] = 0.f;
     const float* __restrict__ wrow = wl + (ci % WL_MAX) * WROW;
 #pragma unroll
     for (int co = 0; co < NCO; ++co) {
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS <= 3 &&
 #pragma unroll
           for (int kw = 0; kw < KS; ++kw) {
 #pragma unroll
-            for (int p = 0; p < 4; ++p) acc[p] = fmaf(wv[kh * KS + kw], nb[co][kh][p + kw], acc[p]);
+            for (int p = 0; p < PX; ++p) acc[p] = fmaf(wv[kh * KS + kw], nb[co][kh][p + kw], acc[p]);
           }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -208,24 +212,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS <= 3 &&
     const int64_t zi = ((int64_t)b * Cin + ci) * HW + (int64_t)gy * W + gx0;
     if (zprev) {
       if (full && (W & 3) == 0) {
-        const float4 zv = *reinterpret_cast<const float4*>(zprev + zi);
-        acc[0] *= zv.x; acc[1] *= zv.y; acc[2] *= zv.z; acc[3] *= zv.w;
+#pragma unroll
+        for (int q = 0; q < PX / 4; ++q) {
+          const float4 zv = *reinterpret_cast<const float4*>(zprev + zi + 4 * q);
+          acc[4 * q] *= zv.x; acc[4 * q + 1] *= zv.y; acc[4 * q + 2] *= zv.z; acc[4 * q + 3] *= zv.w;
+        }
       } else {
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int p = 0; p < PX; ++p)
           if (gx0 + p < W) acc[p] *= zprev[zi + p];
       }
     }
     if constexpr (R2) {
+      // un-shuffle: channel ci*4 + (y%2)*2 + x%2 at (y/2, x/2): even pixels -> plane j=0, odd pixels -> plane j=1
       const int Ho = H >> 1, Wo = W >> 1;
       const int64_t base = ((((int64_t)b * Cin + ci) * 4 + (gy & 1) * 2) * Ho + (gy >> 1)) * (int64_t)Wo + (gx0 >> 1);
-      *reinterpret_cast<float2*>(out + base) = make_float2(acc[0], acc[2]);
-      *reinterpret_cast<float2*>(out + base + (int64_t)Ho * Wo) = make_float2(acc[1], acc[3]);
+      if constexpr (PX == 8) {
+        *reinterpret_cast<float4*>(out + base) = make_float4(acc[0], acc[2], acc[4], acc[6]);
+        *reinterpret_cast<float4*>(out + base + (int64_t)Ho * Wo) = make_float4(acc[1], acc[3], acc[5], acc[7]);
+      } else {
+        *reinterpret_cast<float2*>(out + base) = make_float2(acc[0], acc[2]);
+        *reinterpret_cast<float2*>(out + base + (int64_t)Ho * Wo) = make_float2(acc[1], acc[3]);
+      }
     } else if (r == 1) {
 #pragma unroll
-      for (int p = 0; p < 4; ++p)
+      for (int p = 0; p < PX; ++p)
         if (gx0 + p < W) out[zi + p] = acc[p];
-    } else if (r == 2 && full && (W & 3) == 0 && (H & 1) == 0) {
+    } else if (PX == 4 && r == 2 && full && (W & 3) == 0 && (H & 1) == 0) {
       // un-shuffle: channel ci*4 + (y%2)*2 + x%2 at (y/2, x/2): pixels {0,2} -> plane j=0, {1,3} -> plane j=1
       const int Ho = H >> 1, Wo = W >> 1;
       const int64_t base = ((((int64_t)b * Cin + ci) * 4 + (gy & 1) * 2) * Ho + (gy >> 1)) * (int64_t)Wo + (gx0 >> 1);
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS <= 3 &&
     } else {
       const int Ho = H / r, Wo = W / r, rr2 = r * r;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) {
+      for (int p = 0; p < PX; ++p) {
         const int gx = gx0 + p;
         if (gx < W) {
           const int yq = gy / r, xq = gx / r;
@@ -268,20 +281,25 @@ int nq_head_forward(const float* x, const float* wt, int ld, const float* bias, 
 // dy (B,Cout,H,W) -> out = d/dx (B,Cin,H,W) [* gelu'(zprev)] stored PixelUnshuffle(r)-ed
 int nq_head_dgrad(const float* dy, const float* wt, int ld, const float* zprev, float* out, int B, int Cin, int H, int W,
                   int Cout, int k, int r, hipStream_t st) {
-  const int tiles_x = (W + 63) / 64, tiles = tiles_x * ((H + 15) / 16);
-  dim3 g((unsigned)tiles, (unsigned)B), blk(256);
+  // r == 2 fast path: 8 pixels per thread (tile 32 x 64) when W % 8 == 0 and k <= 3, else 4 (tile 16 x 64)
   const bool r2 = (r == 2) && (W % 4 == 0) && (H % 2 == 0);
-#define NQ_HD(KS_, R2_) \
-  do {                                                                                                              \
-    if (Cout <= 3)                                                                                                  \
-      hipLaunchKernelGGL((head_dgrad_kernel<KS_, R2_, 3>), g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, tiles_x); \
-    else                                                                                                            \
-      hipLaunchKernelGGL((head_dgrad_kernel<KS_, R2_, 4>), g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, tiles_x); \
+  const bool px8 = r2 && (W % 8 == 0) && k <= 3;
+  const int th = px8 ? 32 : 16;
+  const int tiles_x = (W + 63) / 64, tiles = tiles_x * ((H + th - 1) / th);
+  dim3 g((unsigned)tiles, (unsigned)B), blk(256);
+#define NQ_HD(KS_, R2_, PX_)                                                                                          \
+  do {                                                                                                                \
+    if (Cout <= 3)                                                                                                    \
+      hipLaunchKernelGGL((head_dgrad_kernel<KS_, R2_, 3, PX_>), g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, \
+                         tiles_x);                                                                                    \
+    else                                                                                                              \
+      hipLaunchKernelGGL((head_dgrad_kernel<KS_, R2_, 4, PX_>), g, blk, 0, st, dy, wt, ld, zprev, out, Cin, H, W, Cout, r, \
+                         tiles_x);                                                                                    \
   } while (0)
   switch (k) {
-    case 1: if (r2) NQ_HD(1, 1); else NQ_HD(1, 0); break;
-    case 3: if (r2) NQ_HD(3, 1); else NQ_HD(3, 0); break;
-    default: if (r2) NQ_HD(5, 1); else NQ_HD(5, 0); break;
+    case 1: if (px8) NQ_HD(1, 1, 8); else if (r2) NQ_HD(1, 1, 4); else NQ_HD(1, 0, 4); break;
+    case 3: if (px8) NQ_HD(3, 1, 8); else if (r2) NQ_HD(3, 1, 4); else NQ_HD(3, 0, 4); break;
+    default: if (r2) NQ_HD(5, 1, 4); else NQ_HD(5, 0, 4); break;
   }
 #undef NQ_HD
   return nq_launch_status();
