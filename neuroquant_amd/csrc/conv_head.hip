@@ -109,12 +109,18 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     if (co >= CO) break;
     const float bv = bias ? bias[co] : 0.f;
     float* __restrict__ yo = y + ((int64_t)b * CO + co) * HW + (int64_t)gy * W + x0 + c4;
+    float o[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      if (x0 + c4 + p < W) {
-        float v = acc[co][p] + bv;
-        yo[p] = (epi == NQ_EPI_TANH) ? tanhf(v) * 0.5f + 0.5f : v;
-      }
+      const float v = acc[co][p] + bv;
+      o[p] = (epi == NQ_EPI_TANH) ? tanhf(v) * 0.5f + 0.5f : v;
+    }
+    if (w4 && x0 + c4 + 3 < W) {
+      *reinterpret_cast<float4*>(yo) = make_float4(o[0], o[1], o[2], o[3]);   // one 16-byte store per channel
+    } else {
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+        if (x0 + c4 + p < W) yo[p] = o[p];
     }
   }
 }
