@@ -115,7 +115,8 @@ inline Fwd3Plan plan_fwd3(int B, int Cin, int H, int W, int Cout) {
   p.nsplit = 1;
   p.per = nchunk;
   if (p.wgs < 256) {
-    int want = (int)((512 + p.wgs - 1) / p.wgs);
+    int want = (int)(512 / p.wgs);   // floor: stay within ONE round of 512 resident workgroups (a second, nearly empty
+                                     // round costs as much as the first)
     if (want > nchunk) want = nchunk;
     p.per = (nchunk + want - 1) / want;
     p.nsplit = (nchunk + p.per - 1) / p.per;
