@@ -617,6 +617,19 @@ def decoder_stack_dd(emb, spec, weights):
 
 
 def conv2d_fused(x, w, b, epilogue=EPI_PLAIN, r=1):
+    if not torch.is_grad_enabled() or not (x.requires_grad or w.requires_grad or (b is not None and b.requires_grad)):
+        # inference (the per-frame evaluation decodes, calibrate_network.py:82-145): no graph to record, and the big
+        # layers can take the bf16x3 kernel like the calibration loop does
+        x, w = _dev(x, "x"), _dev(w, "weight")
+        b = _dev(b, "bias") if b is not None else None
+        cout, cin, k, k2 = w.shape
+        if k != k2 or x.shape[1] != cin:
+            raise ValueError(f"conv shape mismatch: x {tuple(x.shape)} w {tuple(w.shape)}")
+        B, _, H, W = x.shape
+        if _use3(None) and conv3_supported(B, cin, H, W, cout, k):
+            return conv3_forward_raw(x, weight_layout3(w), b, cout, k, epilogue, r)[0]
+        wt, dims, _, _ = weight_layouts(w, False)
+        return conv_forward_raw(x, wt, dims, b, cout, k, epilogue, r)[0]
     return _ConvFn.apply(x, w, b, epilogue, r)
 
 
