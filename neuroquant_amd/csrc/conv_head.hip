@@ -17,6 +17,7 @@
 namespace {
 
 constexpr int MAXCO = 4;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int KS>
@@ -41,11 +42,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
   const float* __restrict__ xb = x + (int64_t)b * Cin * HW;
   const bool w4 = (W & 3) == 0;
 
-  float acc[MAXCO][4];
+  f32x2 acc2[MAXCO][2];
 #pragma unroll
-  for (int co = 0; co < MAXCO; ++co)
-#pragma unroll
-    for (int p = 0; p < 4; ++p) acc[co][p] = 0.f;
+  for (int co = 0; co < MAXCO; ++co) acc2[co][0] = acc2[co][1] = f32x2{0.f, 0.f};
 
   for (int c0 = 0; c0 < Cin; c0 += CCH) {
     __syncthreads();
@@ -94,8 +93,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 #pragma unroll
             for (int kw = 0; kw < KS; ++kw) {
               const float wv = wc[(kh * KS + kw) * ld + co];  // wave-uniform -> scalar load
-#pragma unroll
-              for (int p = 0; p < 4; ++p) acc[co][p] = fmaf(wv, in[p + kw], acc[co][p]);
+              // two pixels per instruction (v_pk_fma_f32: the fp32 vector peak assumes packed math); per element the
+              // same fused multiply-add as fmaf
+              const f32x2 w2 = {wv, wv};
+              acc2[co][0] = __builtin_elementwise_fma(w2, f32x2{in[kw], in[kw + 1]}, acc2[co][0]);
+              acc2[co][1] = __builtin_elementwise_fma(w2, f32x2{in[kw + 2], in[kw + 3]}, acc2[co][1]);
             }
           }
         }
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
     float o[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-      const float v = acc[co][p] + bv;
+      const float v = acc2[co][p >> 1][p & 1] + bv;
       o[p] = (epi == NQ_EPI_TANH) ? tanhf(v) * 0.5f + 0.5f : v;
     }
     if (w4 && x0 + c4 + 3 < W) {
