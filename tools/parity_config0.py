@@ -32,6 +32,13 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--iters", type=int, default=50)
     args = ap.parse_args()
+    res = run(args)
+    print(json.dumps(res, indent=1))
+    sys.exit(0 if res["psnr_diff_q_opt_dB"] < 0.02 else 1)
+
+
+def run(args):
+    """-> result dict; args needs .train_steps, .cpu_threads, .iters (tests/test_hip_parity.py calls this at reduced length)."""
 
     from neuroquant_amd import ops
     from neuroquant_amd.models import HNeRV
@@ -119,8 +126,7 @@ def main():
     res["loss_rel_diff_first3"] = float(rel[:3].max())
     res["loss_rel_diff_max"] = float(rel.max())
     res["psnr_diff_q_opt_dB"] = abs(res["gpu"]["q_opt"] - res["cpu"]["q_opt"])
-    print(json.dumps(res, indent=1))
-    sys.exit(0 if res["psnr_diff_q_opt_dB"] < 0.02 else 1)
+    return res
 
 
 def _decode_fp(model, emb):
