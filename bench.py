@@ -3,17 +3,26 @@
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--global-batch 16]
 
 A step = one phase-2 calibration iteration (AdaRound alpha + regulariser, the 95 % of a 21k run) of HNeRV
 Bunny_1280x640_3M: uint8 frame gather, fake-quant of all 7 layers, decoder forward, L2 loss, full backward,
-d(alpha) + regulariser gradient, Adam.  Per-GPU batch = 2 frames (BASELINE config 1); with N ranks the global batch
-is 2N frames sharded by rank with one RCCL all-reduce over the conv weight gradients (config 3 at N=8) -> weak
-scaling, value = B=2-equivalent iterations/s summed over ranks.  Inputs are synthetic and resident in HBM before the
-timed region; weights are seeded random-init (iteration cost is value-independent).
+d(alpha) + regulariser gradient, Adam.  Inputs are synthetic and resident in HBM before the timed region; weights of the
+timed runs are seeded random-init (iteration cost is value-independent).
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed inside every 5th timed step) and
-`cpu_baseline` (the oracle = CPU restatement of the reference path, timed on this box's host cores).
+Scaling modes:
+  default            weak: per-GPU batch = 2 frames (BASELINE configs[1]; global batch 2N = configs[3] at N = 8), one RCCL
+                     all-reduce over the conv weight gradients; value = B=2-equivalent iterations/s summed over ranks.
+  --global-batch G   strong: the global batch is fixed (configs[3]: G = 16), per-GPU batch = G/N; value = global-batch-G
+                     iterations/s.
+
+Prints ONE JSON line (rank 0) with
+  `roofline`      dominant kernel of the timed (default-precision, bf16x3) run, HIP-event timed inside every 5th step;
+  `fp32`          the same workload re-timed with exact-fp32 MFMA convolutions (NQ_CONV_PRECISION=fp32) and its roofline;
+  `psnr`          BASELINE configs[0] (8 Bunny-derived 640x1280 frames, iters_w = 50) on a checkpoint trained here:
+                  final PSNR of the CPU oracle, the GPU with exact fp32 and the GPU with bf16x3 (bar: within 0.02 dB);
+  `cpu_baseline`  the oracle (CPU restatement of the reference path) timed on this box's host cores on that same run
+                  (48 iterations, first 4 discarded).
 """
 import argparse
 import json
@@ -42,6 +51,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 FLAGS = dict(weight=0.01, b_range=(20, 2), lr=0.003)
+PROF_EVERY = 5   # HIP events around the conv launches of every 5th timed step (the records themselves cost time)
 
 
 def build_model(seed=903, workload="hnerv"):
@@ -60,14 +70,59 @@ def build_model(seed=903, workload="hnerv"):
     return model.eval()
 
 
+def roofline_of(prof, elapsed, K, t_enq, precision, prof_steps):
+    """-> (roofline dict, per-kernel rows) from ops.profile_stop()'s {key: (launches, total_ms)}."""
+    rows = []
+    for key, (cnt, ms) in prof.items():
+        kind, k, cin, cout, H, Wd, Bk, epi = key
+        flops = 2.0 * Bk * cout * cin * k * k * H * Wd
+        rows.append(dict(kernel=kind, k=k, cin=cin, cout=cout, H=H, W=Wd, B=Bk, launches=cnt, avg_ms=ms / cnt, total_ms=ms,
+                         gflop_per_launch=flops / 1e9, tflops=flops / (ms / cnt * 1e-3) / 1e12))
+    if not rows:
+        return None, rows
+    rows.sort(key=lambda r: -r["total_ms"])
+    conv_ms = sum(r["total_ms"] for r in rows)
+    conv_flops = sum(r["gflop_per_launch"] * r["launches"] for r in rows) * 1e9
+    dom = rows[0]
+    is3 = dom["kernel"].endswith("3")
+    peak = PEAK_BF16X3_TFLOPS if is3 else PEAK_F32_MFMA_TFLOPS
+    # HBM bytes per launch of that kernel: PMC passes of the SAME build (profiles/hbm_traffic.json, collected with
+    # rocprofv3 --pmc as profiles/README.md describes).  Only reported while the profiled duration still matches the live
+    # one (a stale table must not outlive a kernel change) and for the per-GPU batch it was taken at; else null.
+    traffic, traffic_src = None, None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            ent = json.load(open(tpath)).get(f'{dom["kernel"]}_k{dom["k"]}_{dom["cin"]}_{dom["cout"]}')
+            if ent and ent.get("batch", 2) == dom["B"] and abs(ent["dur_us"] * 1e-3 - dom["avg_ms"]) <= 0.2 * dom["avg_ms"]:
+                traffic, traffic_src = ent.get("bytes"), ent.get("source")
+        except Exception:
+            traffic = None
+    roofline = dict(bound="mfma", kernel=f'{dom["kernel"]} k{dom["k"]} {dom["cin"]}->{dom["cout"]} {dom["H"]}x{dom["W"]} B{dom["B"]}',
+                    achieved=round(dom["tflops"], 2), peak=round(peak, 1), unit="TFLOP/s",
+                    frac=round(dom["tflops"] / peak, 4), traffic=traffic, traffic_source=traffic_src,
+                    peak_basis=("dense BF16 MFMA 2500 TF / 3 products per fp32-equivalent FLOP (bf16x3)" if is3
+                                else "fp32-input MFMA 157.3 TF"),
+                    avg_launch_ms=round(dom["avg_ms"], 4), gflop_per_launch=round(dom["gflop_per_launch"], 2),
+                    all_conv_tflops=round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
+                    conv_share_of_step=round(conv_ms / max(prof_steps, 1) / (elapsed / K * 1e3), 3),
+                    profiled_steps=prof_steps, host_enqueue_ms_per_step=round(t_enq / K * 1e3, 3))
+    return roofline, rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=132)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: fixed global batch (BASELINE configs[3]: 16), per-GPU batch = G/N; default 0 = weak "
+                         "scaling with 2 frames per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the psnr / cpu_baseline leg (CPU oracle, ~1 min)")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the exact-fp32 re-timing")
+    ap.add_argument("--fp32-steps", type=int, default=10)
+    ap.add_argument("--psnr-train-steps", type=int, default=1200)
     ap.add_argument("--workload", choices=("hnerv", "nerv"), default="hnerv",
                     help="hnerv = the headline config (default); nerv = NeRV-3M + Hadamard (BASELINE configs[2]), no cpu baseline")
     args = ap.parse_args()
@@ -89,109 +144,100 @@ def main():
     from neuroquant_amd.quantization import QuantModel, model_reconstruction
     from neuroquant_amd.utils import CacheLoader, FrameCache, synthetic_frames
 
-    B = 2                       # frames per GPU per iteration (BASELINE config 1)
-    gB = B * world
+    strong = args.global_batch > 0
+    if strong:
+        if args.global_batch % world:
+            raise SystemExit(f"--global-batch {args.global_batch} does not divide over {world} ranks")
+        gB = args.global_batch
+        B = gB // world
+    else:
+        B = 2                   # frames per GPU per iteration (BASELINE configs[1])
+        gB = B * world
     K, W = args.steps, args.warmup
     n_frames = max(args.frames // gB * gB, gB)
+    nerv = args.workload == "nerv"
 
     # ---- workload, resident in HBM ----
-    nerv = args.workload == "nerv"
-    model = build_model(workload=args.workload)
-    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("encoder")}
-    model = model.to(dev)
     frames_u8 = synthetic_frames(n_frames, 640, 1280, seed=903, device=dev)
     cache = FrameCache(frames_u8)
-    with torch.no_grad():
-        if nerv:
-            emb = model.encode(torch.arange(n_frames, device=dev).float() / n_frames)
-        else:
-            emb = torch.cat([model.encode(cache.batch(torch.arange(i, min(i + 4, n_frames), device=dev)))
-                             for i in range(0, n_frames, 4)])
-    qnn = QuantModel(model, hadamard=nerv, weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
-    avg_bits = qnn.set_bitwidth(BITS)
-    qnn.eval()
-    qnn.set_quant_state(True)
-    with torch.no_grad():
-        qnn(emb[:B])            # lazy scale init (calibrate_network.py:235-238)
-
-    steps_total = W + K
-    # one "epoch" of W+K+1 batches (shuffled passes over the frames chained): iters = len(loader) gives
-    # int(0.05*iters/len) = 0 phase-1 epochs and exactly one phase-2 epoch, for any K
-    loader = CacheLoader(cache, list(range(n_frames)), gB, seed=903, rank=rank, world=world, epoch_batches=steps_total + 1)
-    iters = len(loader)
-
-    t = {}
+    emb_box = {}
 
     def sync():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    PROF_EVERY = 5   # HIP events around the conv launches of every 5th timed step (the records themselves cost time)
+    def timed_run(precision, K, W):
+        """Fresh QuantModel on the seeded weights; W untimed + K timed phase-2 iterations under `precision`."""
+        ops.set_conv_precision(precision)
+        model = build_model(workload=args.workload).to(dev)
+        if "emb" not in emb_box:
+            with torch.no_grad():
+                if nerv:
+                    emb_box["emb"] = model.encode(torch.arange(n_frames, device=dev).float() / n_frames)
+                else:
+                    emb_box["emb"] = torch.cat([model.encode(cache.batch(torch.arange(i, min(i + 4, n_frames), device=dev)))
+                                                for i in range(0, n_frames, 4)])
+        emb = emb_box["emb"]
+        qnn = QuantModel(model, hadamard=nerv, weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
+        avg_bits = qnn.set_bitwidth(BITS)
+        qnn.eval()
+        qnn.set_quant_state(True)
+        with torch.no_grad():
+            qnn(emb[:B])            # lazy scale init (calibrate_network.py:235-238)
+        steps_total = W + K
+        # one "epoch" of W+K+1 batches (shuffled passes over the frames chained): iters = len(loader) gives
+        # int(0.05*iters/len) = 0 phase-1 epochs and exactly one phase-2 epoch, for any K
+        loader = CacheLoader(cache, list(range(n_frames)), gB, seed=903, rank=rank, world=world, epoch_batches=steps_total + 1)
+        t = {}
 
-    def hook(done):
-        if W < done < steps_total:
-            ops.profile_sample((done - W) % PROF_EVERY == 0)
-        if done == W:
-            sync()
-            if not os.environ.get("NQ_BENCH_NOPROF"):
-                ops.profile_start()
-            t["t0"] = time.perf_counter()
-        elif done == steps_total:
-            t["t_enq"] = time.perf_counter()   # host finished enqueueing the timed steps (before the device drains)
-            sync()
-            t["t1"] = time.perf_counter()
-            t["prof"] = ops.profile_stop() if not os.environ.get("NQ_BENCH_NOPROF") else {}
+        def hook(done):
+            if W < done < steps_total:
+                ops.profile_sample((done - W) % PROF_EVERY == 0)
+            if done == W:
+                sync()
+                if not os.environ.get("NQ_BENCH_NOPROF"):
+                    ops.profile_start()
+                t["t0"] = time.perf_counter()
+            elif done == steps_total:
+                t["t_enq"] = time.perf_counter()   # host finished enqueueing the timed steps (before the device drains)
+                sync()
+                t["t1"] = time.perf_counter()
+                t["prof"] = ops.profile_stop() if not os.environ.get("NQ_BENCH_NOPROF") else {}
 
-    model_reconstruction(qnn, cali_data=emb, gt=loader, arch=args.workload, batch_size=gB, iters=iters, hadamard=nerv,
-                         warmup=0.0, max_steps=steps_total, step_hook=hook, **FLAGS)
-    if "t1" not in t:
-        hook(steps_total)
-    elapsed = t["t1"] - t["t0"]
-    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if use_dist:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+        model_reconstruction(qnn, cali_data=emb, gt=loader, arch=args.workload, batch_size=gB, iters=len(loader),
+                             hadamard=nerv, warmup=0.0, max_steps=steps_total, step_hook=hook, **FLAGS)
+        if "t1" not in t:
+            hook(steps_total)
+        ops.set_conv_precision(None)
+        elapsed = t["t1"] - t["t0"]
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        if use_dist:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        prof_steps = len([d for d in range(W, steps_total) if (d - W) % PROF_EVERY == 0])
+        del qnn, model
+        torch.cuda.empty_cache()
+        return dict(elapsed=float(tmax.item()), t_enq=t["t_enq"] - t["t0"], prof=t["prof"], avg_bits=avg_bits,
+                    prof_steps=prof_steps)
+
+    main_run = timed_run("bf16x3", K, W)
+    fp32_run = None
+    if not args.no_fp32:
+        Kf = max(1, min(K, args.fp32_steps))
+        fp32_run = (timed_run("fp32", Kf, min(W, 2)), Kf)
 
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel (HIP events recorded around every conv launch of the timed steps) ----
-    prof = t["prof"]
-    rows = []
-    for key, (cnt, ms) in prof.items():
-        kind, k, cin, cout, H, Wd, Bk, epi = key
-        flops = 2.0 * Bk * cout * cin * k * k * H * Wd
-        rows.append(dict(kernel=kind, k=k, cin=cin, cout=cout, H=H, W=Wd, launches=cnt, avg_ms=ms / cnt, total_ms=ms,
-                         gflop_per_launch=flops / 1e9, tflops=flops / (ms / cnt * 1e-3) / 1e12))
-    rows.sort(key=lambda r: -r["total_ms"])
-    conv_ms = sum(r["total_ms"] for r in rows)
-    conv_flops = sum(r["gflop_per_launch"] * r["launches"] for r in rows) * 1e9
-    if not rows:   # NQ_BENCH_NOPROF=1: throughput only (measures the cost of the event records themselves)
-        print(json.dumps({"value": round(K * world / elapsed, 3), "ms_per_step": round(elapsed / K * 1e3, 3), "note": "no profiling"}))
+    elapsed = main_run["elapsed"]
+    per_step_units = 1 if strong else world     # strong: one global-batch iteration per step; weak: `world` B=2-equivalents
+    if os.environ.get("NQ_BENCH_NOPROF"):   # throughput only (measures the cost of the event records themselves)
+        print(json.dumps({"value": round(K * per_step_units / elapsed, 3), "ms_per_step": round(elapsed / K * 1e3, 3),
+                          "note": "no profiling"}))
         return
-    dom = rows[0]
-    prof_steps = len([d for d in range(W, steps_total) if (d - W) % PROF_EVERY == 0])
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get(f'{dom["kernel"]}_k{dom["k"]}_{dom["cin"]}_{dom["cout"]}', {}).get("bytes")
-        except Exception:
-            traffic = None
-    is3 = dom["kernel"].endswith("3")
-    peak = PEAK_BF16X3_TFLOPS if is3 else PEAK_F32_MFMA_TFLOPS
-    roofline = dict(bound="mfma", kernel=f'{dom["kernel"]} k{dom["k"]} {dom["cin"]}->{dom["cout"]} {dom["H"]}x{dom["W"]}',
-                    achieved=round(dom["tflops"], 2), peak=round(peak, 1), unit="TFLOP/s",
-                    frac=round(dom["tflops"] / peak, 4), traffic=traffic,
-                    peak_basis=("dense BF16 MFMA 2500 TF / 3 products per fp32-equivalent FLOP (bf16x3)" if is3
-                                else "fp32-input MFMA 157.3 TF"),
-                    avg_launch_ms=round(dom["avg_ms"], 4), gflop_per_launch=round(dom["gflop_per_launch"], 2),
-                    all_conv_tflops=round(conv_flops / (conv_ms * 1e-3) / 1e12, 2),
-                    conv_share_of_step=round(conv_ms / prof_steps / (elapsed / K * 1e3), 3), profiled_steps=prof_steps,
-                    host_enqueue_ms_per_step=round((t["t_enq"] - t["t0"]) / K * 1e3, 3))
+    roofline, rows = roofline_of(main_run["prof"], elapsed, K, main_run["t_enq"], "bf16x3", main_run["prof_steps"])
     try:  # per-kernel table for DESIGN.md / profiles (scratch; not part of the contract line)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", f"bench_kernels_n{world}.json"), "w") as f:
@@ -199,24 +245,40 @@ def main():
     except OSError:
         pass
 
-    # ---- CPU baseline: the oracle (restatement of the reference's PyTorch-CPU path) on this box's host cores ----
-    cpu = None
-    if world == 1 and not args.no_cpu_baseline and not nerv:
-        cpu = cpu_baseline(sd_cpu, frames_u8[:8], emb[:8], args.cpu_iters)
+    fp32 = None
+    if fp32_run is not None:
+        r, Kf = fp32_run
+        rl, rows32 = roofline_of(r["prof"], r["elapsed"], Kf, r["t_enq"], "fp32", r["prof_steps"])
+        fp32 = {"value": round(Kf * per_step_units / r["elapsed"], 3), "ms_per_step": round(r["elapsed"] / Kf * 1e3, 3),
+                "steps": Kf, "dtype": "f32 (exact fp32-input MFMA, NQ_CONV_PRECISION=fp32)", "roofline": rl}
+        try:
+            with open(os.path.join(ROOT, "gpurun_out", f"bench_kernels_fp32_n{world}.json"), "w") as f:
+                json.dump(rows32, f, indent=1)
+        except OSError:
+            pass
 
-    value = K * world / elapsed
+    # ---- PSNR vs the CPU oracle + CPU baseline timing (BASELINE configs[0]); single GPU, headline workload only ----
+    psnr = cpu = None
+    if world == 1 and not args.no_cpu_baseline and not nerv:
+        psnr, cpu = psnr_and_cpu_baseline(dev, args.psnr_train_steps)
+
+    value = K * per_step_units / elapsed
     out = {
         "metric": "calibration iters/sec (HNeRV Bunny 1280x640, 21k iters) + final PSNR vs ref",
-        "value": round(value, 3), "unit": "it/s (B=2 frames per iteration-equivalent, summed over GPUs)",
+        "value": round(value, 3),
+        "unit": (f"it/s (global batch {gB} frames per iteration, sharded over the GPUs)" if strong
+                 else "it/s (B=2 frames per iteration-equivalent, summed over GPUs)"),
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f32 operands split into bf16 hi+lo, 3 BF16 MFMAs per product, fp32 accumulate (bf16x3); fp32 MFMA on small layers",
         "data": "synthetic",
         "config": {"workload": ("NeRV Bunny_1280x640_3M + Hadamard" if nerv else "HNeRV Bunny_1280x640_3M")
                    + ", channel_wise, bits 6 5 4 5 5 6 6, phase-2 (AdaRound) iteration",
-                   "per_gpu_batch": B, "global_batch": gB, "frames": n_frames, "avg_bits": avg_bits,
+                   "per_gpu_batch": B, "global_batch": gB, "frames": n_frames, "avg_bits": main_run["avg_bits"],
                    "parallelism": f"dp{world}"},
         "roofline": roofline,
+        "fp32": fp32,
+        "psnr": psnr,
         "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)
@@ -224,34 +286,47 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(sd, frames_u8, emb, n_iters):
-    """Time the oracle's phase-2 iteration on the same HNeRV-3M weights / first 8 frames, all host cores."""
-    import numpy as np
-    from oracle import nq_oracle as O
-    # the box's CPU share for one GPU is 16 cores (os.cpu_count() reports the whole 256-thread host; oversubscribing
-    # it made the oracle 10x slower), so use the affinity mask capped at 16
+def psnr_and_cpu_baseline(dev, train_steps):
+    """BASELINE configs[0]: HNeRV-3M, 8 frames, --precision 6 5 4 5 5 6 6, iters_w = 50 (0 phase-1 epochs + 12 phase-2
+    epochs = 48 iterations), on a checkpoint fitted here (untimed set-up): GPU exact fp32, GPU bf16x3 and the CPU oracle on
+    the same checkpoint / frames / recorded batch order.  The oracle run doubles as the CPU baseline: iterations 5..48
+    timed, all host cores of this box's share."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import precision_gate as pg
     try:
         avail = len(os.sched_getaffinity(0))
     except AttributeError:
         avail = os.cpu_count() or 1
+    # the box's CPU share for one GPU is 16 cores (os.cpu_count() reports the whole host; oversubscribing it made the
+    # oracle 10x slower), so use the affinity mask capped at 16
     cores = max(1, min(avail, 16))
-    torch.set_num_threads(cores)
-    dec = O.Decoder.from_state_dict(sd, "hnerv", HNERV_3M["dec_strides"])
-    qs = O.QuantStack(dec, BITS, hadamard=False)
-    frames = frames_u8.cpu().float() / 255.0
-    order = np.array([[[0, 1], [2, 3], [4, 5], [6, 7]]] * 4)
-    # iters=50 -> 0 phase-1 epochs, phase-2 iterations only (BASELINE config 0 shape); 1 untimed + n timed
-    t0 = time.perf_counter()
-    O.calibrate(qs, emb.cpu(), frames, order, 50, warmup=0.0, max_steps=1, **FLAGS)
-    t1 = time.perf_counter()
-    qs2 = O.QuantStack(O.Decoder.from_state_dict(sd, "hnerv", HNERV_3M["dec_strides"]), BITS, hadamard=False)
-    t2 = time.perf_counter()
-    O.calibrate(qs2, emb.cpu(), frames, order, 50, warmup=0.0, max_steps=1 + n_iters, **FLAGS)
-    t3 = time.perf_counter()
-    per_iter = ((t3 - t2) - (t1 - t0)) / n_iters
-    return {"value": round(1.0 / per_iter, 4), "unit": "it/s", "cores": cores, "kind": "port",
-            "sample": f"{n_iters} phase-2 iterations (B=2) of the same HNeRV-3M workload after 1 untimed, oracle on "
-                      f"torch-CPU with {cores} threads, {per_iter:.2f} s/iter"}
+    n, B, iters = 8, 2, 50
+    frames_u8 = pg.bunny_frames_640(dev, n)
+    model, emb, fp_psnr = pg.train_checkpoint(frames_u8, train_steps, dev, log=lambda s: print(s, file=sys.stderr, flush=True))
+    order = pg.make_order(n, B, iters)
+    g32, _, _ = pg.calibrate_gpu(model, frames_u8, emb, order, iters, "fp32", record=False)
+    g3, _, _ = pg.calibrate_gpu(model, frames_u8, emb, order, iters, "bf16x3", record=False)
+    stamps = {}
+
+    def on_step(done):
+        stamps[done] = time.perf_counter()
+
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    c, clog, _ = pg.calibrate_oracle(sd, frames_u8, emb, order, iters, cores, on_step=on_step)
+    t_end = time.perf_counter()
+    n_it = len(clog)
+    skip = 4
+    per_iter = (t_end - stamps[skip]) / (n_it - skip)
+    psnr = {"config": f"BASELINE configs[0]: HNeRV-3M, {n} Bunny-derived 640x1280 frames, B={B}, iters_w={iters} ({n_it} "
+                      f"phase-2 iterations), checkpoint fitted here for {train_steps} steps",
+            "fp_model": round(fp_psnr, 4), "q_noopt": round(c["q_noopt"], 4),
+            "oracle": round(c["q_opt"], 4), "fp32": round(g32["q_opt"], 4), "bf16x3": round(g3["q_opt"], 4),
+            "max_abs_diff_dB": round(max(abs(g32["q_opt"] - c["q_opt"]), abs(g3["q_opt"] - c["q_opt"])), 5),
+            "tolerance_dB": 0.02}
+    cpu = {"value": round(1.0 / per_iter, 4), "unit": "it/s", "cores": cores, "kind": "port",
+           "sample": f"configs[0]: {n_it} phase-2 iterations (B=2) of HNeRV-3M at 640x1280, first {skip} discarded, oracle on "
+                     f"torch-CPU with {cores} threads, {per_iter:.2f} s/iter; final PSNR compared in `psnr`"}
+    return psnr, cpu
 
 
 if __name__ == "__main__":

@@ -12,7 +12,9 @@
  *   - no allocation, no ownership transfer, no host synchronisation: the caller passes outputs and
  *     workspaces; work is enqueued on `stream` (a hipStream_t) and the call returns immediately;
  *   - returns NQ_OK (0) or a negative NQ_ERR_* code; nothing throws across the boundary;
- *   - stateless and re-entrant; pointers must be 16-byte aligned unless stated otherwise.
+ *   - re-entrant from any thread and device; the only thing the library remembers is, per kernel and per device, that
+ *     the >64 KB dynamic-LDS opt-in has been granted (lock-free, idempotent); pointers must be 16-byte aligned unless
+ *     stated otherwise.
  *
  * "rows x row_len" tensors: a weight (C_out, C_in, k, k) is rows=C_out, row_len=C_in*k*k; a bias is
  * rows=1, row_len=C_out.  per_row=1 -> delta/zp hold one value per row (channel-wise weight),
@@ -49,9 +51,10 @@ int nq_scale_init_max(const float* x, int64_t rows, int64_t row_len, int n_level
 int nq_uaq_forward(const float* x, const float* delta, const float* zp, float* y, int64_t rows, int64_t row_len,
                    int per_row, int n_levels, nq_stream_t stream);
 
-/* Backward of the above w.r.t. delta (round_ste, quantizer.py:53-57): ddelta[row] = sum gy*((xq-zp) -
- * 1{0<=rint(x/delta)+zp<=L-1} * x/delta).  ddelta is overwritten (rows values, or 1 if !per_row). */
-int nq_uaq_backward(const float* x, const float* gy, const float* delta, const float* zp, float* ddelta,
+/* Backward of the above (round_ste, quantizer.py:53-57): ddelta[row] = sum gy*((xq-zp) -
+ * 1{0<=rint(x/delta)+zp<=L-1} * x/delta), overwritten (rows values, or 1 if !per_row); dx (may be NULL; same shape as x)
+ * = gy * 1{0<=rint(x/delta)+zp<=L-1}, the straight-through gradient w.r.t. the quantiser input. */
+int nq_uaq_backward(const float* x, const float* gy, const float* delta, const float* zp, float* ddelta, float* dx,
                     int64_t rows, int64_t row_len, int per_row, int n_levels, nq_stream_t stream);
 
 /* AdaRoundQuantizer.__init__/init_alpha (quantizer.py:264-265, 305-314): delta/zp through an fp16 round

@@ -49,7 +49,7 @@ def _load():
     sig("nq_error_string", c_char_p, I)
     sig("nq_scale_init_max", I, P, L, L, I, P, P, P)
     sig("nq_uaq_forward", I, P, P, P, P, L, L, I, I, P)
-    sig("nq_uaq_backward", I, P, P, P, P, P, L, L, I, I, P)
+    sig("nq_uaq_backward", I, P, P, P, P, P, P, L, L, I, I, P)
     sig("nq_adaround_init", I, P, P, P, P, P, P, L, L, I, P)
     sig("nq_adaround_forward", I, P, P, P, P, P, P, L, L, I, I, I, P)
     sig("nq_adaround_backward", I, P, P, P, P, P, P, L, L, I, I, F, F, P)

@@ -493,13 +493,7 @@ int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
     a.lds_epi = 1;
     if (lds < (size_t)MT * 1024) lds = (size_t)MT * 1024;
   }
-  static size_t attr_lds = 64 * 1024;  // more dynamic LDS than the default limit needs an explicit opt-in
-  if (lds > attr_lds) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm3_kernel<MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return NQ_ERR_LAUNCH;
-    attr_lds = lds;
-  }
+  if (int rc = nq_lds_optin<&conv_igemm3_kernel<MI>>(lds)) return rc;
   hipLaunchKernelGGL(conv_igemm3_kernel<MI>, dim3((unsigned)tiles, (unsigned)a.co_tiles, (unsigned)(a.B * a.nsplit)), dim3(256),
                      lds, st, a);
   return nq_launch_status();

@@ -454,13 +454,7 @@ int launch_igemm(const ConvArgs& a, int tiles, int co_tiles, hipStream_t st) {
     return v;
   }();
   size_t lds = (size_t)(2 * PATCH_FLOATS + 2 * WROWS1 * khs_for(MI) * LDW) * sizeof(float);
-  static bool attr_set = false;  // > 64 KB of dynamic LDS needs an explicit opt-in (idempotent)
-  if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<MI>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return NQ_ERR_LAUNCH;
-    attr_set = true;
-  }
+  if (int rc = nq_lds_optin<&conv_igemm_kernel<MI>>(lds)) return rc;
   hipLaunchKernelGGL(conv_igemm_kernel<MI>, dim3((unsigned)tiles, (unsigned)co_tiles, (unsigned)(a.B * a.nsplit)), dim3(256), lds, st,
                      a);
   return nq_launch_status();

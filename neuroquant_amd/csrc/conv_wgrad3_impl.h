@@ -345,13 +345,7 @@ int launch_wgrad3(const Wgrad3Args& a, hipStream_t st) {
   constexpr int BUF_BYTES = 2 * 4 * MT * 16 + ((CIT * PSX * 4 + 15) / 16) * 16;
   size_t lds = (size_t)2 * BUF_BYTES;
   dim3 grid((unsigned)a.nsplit, (unsigned)(a.n_pad / NT), (unsigned)(a.co_pad / MT));
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad3_kernel<MI, NI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return NQ_ERR_LAUNCH;
-    attr_set = true;
-  }
+  if (int rc = nq_lds_optin<&conv_wgrad3_kernel<MI, NI>>(lds)) return rc;
   hipLaunchKernelGGL((conv_wgrad3_kernel<MI, NI>), grid, dim3(256), lds, st, a);
   return nq_launch_status();
 }

@@ -265,13 +265,7 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   constexpr int CIT = (NT + KK - 2) / KK + 1;
   size_t lds = (size_t)2 * (MT * LDP + CIT * PSX) * sizeof(float);
   dim3 grid((unsigned)a.nsplit, (unsigned)(a.n_pad / NT), (unsigned)(a.co_pad / MT));
-  static bool attr_set = false;  // > 64 KB of dynamic LDS needs an explicit opt-in (idempotent, so a race is harmless)
-  if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_kernel<MI, NI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return NQ_ERR_LAUNCH;
-    attr_set = true;
-  }
+  if (int rc = nq_lds_optin<&conv_wgrad_kernel<MI, NI>>(lds)) return rc;
   hipLaunchKernelGGL((conv_wgrad_kernel<MI, NI>), grid, dim3(256), lds, st, a);
   return nq_launch_status();
 }

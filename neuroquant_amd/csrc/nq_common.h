@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/nq_hip.h"
 
 #define NQ_WAVE 64
@@ -13,6 +15,25 @@ static inline int nq_launch_status() {
 }
 
 static inline hipStream_t nq_s(nq_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// More than 64 KB of dynamic LDS needs an explicit opt-in on the kernel, per device.  One table per kernel (the template
+// argument IS the kernel) and per device; lock-free, and the attribute call is idempotent, so concurrent callers on any
+// thread / device are safe: the library keeps no other state.
+template <auto Kernel>
+static inline int nq_lds_optin(size_t lds) {
+  if (lds <= 64 * 1024) return NQ_OK;
+  static std::atomic<size_t> granted[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return NQ_ERR_LAUNCH;
+  std::atomic<size_t>& g = granted[dev & 63];
+  if (g.load(std::memory_order_acquire) >= lds) return NQ_OK;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return NQ_ERR_LAUNCH;
+  size_t cur = g.load(std::memory_order_relaxed);
+  while (cur < lds && !g.compare_exchange_weak(cur, lds, std::memory_order_release)) {
+  }
+  return NQ_OK;
+}
 
 // exact-erf GELU and its derivative from ONE erf (nn.GELU(), reference models/_layers.py:104-105).  The forward
 // epilogues store the derivative ("dact") next to the activation, so no backward kernel evaluates erf/exp again.

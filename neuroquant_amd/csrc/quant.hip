@@ -47,12 +47,12 @@ __global__ __launch_bounds__(TPB) void scale_init_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void uaq_fwd_kernel(const float* __restrict__ x, const float* __restrict__ delta,
                                                       const float* __restrict__ zp, float* __restrict__ y,
-                                                      int64_t row_len, int per_row, float qmax) {
-  const int64_t row = blockIdx.y;
+                                                      int64_t row_len, int per_row, float qmax, unsigned bpr) {
+  const int64_t row = blockIdx.x / bpr;   // rows are folded into grid.x (no 65535-row limit of grid.y)
   const float d = per_row ? delta[row] : delta[0];
   const float z = per_row ? zp[row] : zp[0];
   const int64_t base = row * row_len;
-  int64_t i = (int64_t)blockIdx.x * (TPB * EPT) + threadIdx.x;
+  int64_t i = (int64_t)(blockIdx.x - row * bpr) * (TPB * EPT) + threadIdx.x;
 #pragma unroll
   for (int e = 0; e < EPT; ++e, i += TPB) {
     if (i < row_len) {
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(TPB) void uaq_fwd_kernel(const float* __restrict__ 
 
 __global__ __launch_bounds__(TPB) void uaq_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                       const float* __restrict__ delta, const float* __restrict__ zp,
-                                                      float* __restrict__ ddelta, int64_t row_len, int per_row,
-                                                      float qmax) {
+                                                      float* __restrict__ ddelta, float* __restrict__ dx,
+                                                      int64_t row_len, int per_row, float qmax) {
   __shared__ float red[16];
   const int64_t row = blockIdx.x;
   const float d = per_row ? delta[row] : delta[0];
@@ -78,7 +78,9 @@ __global__ __launch_bounds__(TPB) void uaq_bwd_kernel(const float* __restrict__ 
     float xi = rintf(u) + z;
     float xq = fminf(fmaxf(xi, 0.f), qmax);
     float inside = (xi >= 0.f && xi <= qmax) ? 1.f : 0.f;
-    acc += gy[base + i] * ((xq - z) - inside * u);
+    const float g = gy[base + i];
+    acc += g * ((xq - z) - inside * u);
+    if (dx) dx[base + i] = g * inside;   // round_ste: straight-through inside the clamp range (quantizer.py:53-57, 118)
   }
   float s = nq_block_sum(acc, red);
   if (threadIdx.x == 0) ddelta[row] = s;
@@ -101,11 +103,11 @@ __global__ void adaround_scale_kernel(const float* __restrict__ din, const float
 __global__ __launch_bounds__(TPB) void adaround_alpha_init_kernel(const float* __restrict__ x,
                                                                   const float* __restrict__ delta,
                                                                   float* __restrict__ alpha, int64_t row_len,
-                                                                  int per_row) {
-  const int64_t row = blockIdx.y;
+                                                                  int per_row, unsigned bpr) {
+  const int64_t row = blockIdx.x / bpr;
   const float d = per_row ? delta[row] : delta[0];
   const int64_t base = row * row_len;
-  int64_t i = (int64_t)blockIdx.x * (TPB * EPT) + threadIdx.x;
+  int64_t i = (int64_t)(blockIdx.x - row * bpr) * (TPB * EPT) + threadIdx.x;
 #pragma unroll
   for (int e = 0; e < EPT; ++e, i += TPB) {
     if (i < row_len) {
@@ -149,12 +151,12 @@ __global__ __launch_bounds__(TPB) void adaround_fwd_kernel(const float* __restri
                                                            const float* __restrict__ delta,
                                                            const float* __restrict__ zp, float* __restrict__ y,
                                                            float* __restrict__ xq_out, int64_t row_len, int per_row,
-                                                           float qmax, int soft) {
-  const int64_t row = blockIdx.y;
+                                                           float qmax, int soft, unsigned bpr) {
+  const int64_t row = blockIdx.x / bpr;   // rows are folded into grid.x (no 65535-row limit of grid.y)
   const float d = per_row ? delta[row] : delta[0];
   const float z = per_row ? zp[row] : zp[0];
   const int64_t base = row * row_len;
-  int64_t i = (int64_t)blockIdx.x * (TPB * EPT) + threadIdx.x;
+  int64_t i = (int64_t)(blockIdx.x - row * bpr) * (TPB * EPT) + threadIdx.x;
 #pragma unroll
   for (int e = 0; e < EPT; ++e, i += TPB) {
     if (i < row_len) {
@@ -170,12 +172,12 @@ __global__ __launch_bounds__(TPB) void adaround_bwd_kernel(const float* __restri
                                                            const float* __restrict__ delta,
                                                            const float* __restrict__ zp, float* __restrict__ dalpha,
                                                            int64_t row_len, int per_row, float qmax, float reg_weight,
-                                                           float reg_b) {
-  const int64_t row = blockIdx.y;
+                                                           float reg_b, unsigned bpr) {
+  const int64_t row = blockIdx.x / bpr;   // rows are folded into grid.x (no 65535-row limit of grid.y)
   const float d = per_row ? delta[row] : delta[0];
   const float z = per_row ? zp[row] : zp[0];
   const int64_t base = row * row_len;
-  int64_t i = (int64_t)blockIdx.x * (TPB * EPT) + threadIdx.x;
+  int64_t i = (int64_t)(blockIdx.x - row * bpr) * (TPB * EPT) + threadIdx.x;
 #pragma unroll
   for (int e = 0; e < EPT; ++e, i += TPB) {
     if (i < row_len) {
@@ -320,16 +322,18 @@ __global__ __launch_bounds__(TPB) void adam_multi_kernel(AdamMulti t, float step
     if (i < sg.n) adam_elem(sg.p, sg.g, sg.m, sg.v, i, step_size, beta1, beta2, eps, bc2_sqrt);
 }
 
-inline dim3 row_grid(int64_t rows, int64_t row_len) {
-  return dim3((unsigned)((row_len + TPB * EPT - 1) / (TPB * EPT)), (unsigned)rows, 1);
+inline unsigned blocks_per_row(int64_t row_len) { return (unsigned)((row_len + TPB * EPT - 1) / (TPB * EPT)); }
+inline dim3 row_grid(int64_t rows, int64_t row_len) { return dim3((unsigned)(rows * blocks_per_row(row_len)), 1, 1); }
+// rows x blocks-per-row must fit grid.x (2^31 - 1); any channel count a decoder can have does
+inline bool bad_rows(int64_t rows, int64_t row_len) {
+  return rows <= 0 || row_len <= 0 || rows * (int64_t)blocks_per_row(row_len) > 0x7fffffffLL;
 }
-inline bool bad_rows(int64_t rows, int64_t row_len) { return rows <= 0 || row_len <= 0 || rows > 65535; }
 
 }  // namespace
 
 extern "C" {
 
-int nq_abi_version(void) { return 1; }
+int nq_abi_version(void) { return 2; }
 
 const char* nq_error_string(int code) {
   switch (code) {
@@ -353,16 +357,16 @@ int nq_uaq_forward(const float* x, const float* delta, const float* zp, float* y
                    int per_row, int n_levels, nq_stream_t stream) {
   if (!x || !delta || !zp || !y || bad_rows(rows, row_len)) return NQ_ERR_INVALID;
   hipLaunchKernelGGL(uaq_fwd_kernel, row_grid(rows, row_len), dim3(TPB), 0, nq_s(stream), x, delta, zp, y, row_len,
-                     per_row, (float)(n_levels - 1));
+                     per_row, (float)(n_levels - 1), blocks_per_row(row_len));
   return nq_launch_status();
 }
 
-int nq_uaq_backward(const float* x, const float* gy, const float* delta, const float* zp, float* ddelta, int64_t rows,
-                    int64_t row_len, int per_row, int n_levels, nq_stream_t stream) {
+int nq_uaq_backward(const float* x, const float* gy, const float* delta, const float* zp, float* ddelta, float* dx,
+                    int64_t rows, int64_t row_len, int per_row, int n_levels, nq_stream_t stream) {
   if (!x || !gy || !delta || !zp || !ddelta || rows <= 0 || row_len <= 0) return NQ_ERR_INVALID;
   // per_row=0 -> the whole tensor is one reduction row
   int64_t r = per_row ? rows : 1, len = per_row ? row_len : rows * row_len;
-  hipLaunchKernelGGL(uaq_bwd_kernel, dim3((unsigned)r), dim3(TPB), 0, nq_s(stream), x, gy, delta, zp, ddelta, len,
+  hipLaunchKernelGGL(uaq_bwd_kernel, dim3((unsigned)r), dim3(TPB), 0, nq_s(stream), x, gy, delta, zp, ddelta, dx, len,
                      per_row, (float)(n_levels - 1));
   return nq_launch_status();
 }
@@ -374,7 +378,7 @@ int nq_adaround_init(const float* x, const float* delta_in, const float* zp_in, 
   hipLaunchKernelGGL(adaround_scale_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, nq_s(stream), delta_in,
                      zp_in, delta_out, zp_out, ns);
   hipLaunchKernelGGL(adaround_alpha_init_kernel, row_grid(rows, row_len), dim3(TPB), 0, nq_s(stream), x, delta_out,
-                     alpha, row_len, per_row);
+                     alpha, row_len, per_row, blocks_per_row(row_len));
   return nq_launch_status();
 }
 
@@ -382,7 +386,7 @@ int nq_adaround_forward(const float* x, const float* alpha, const float* delta, 
                         int64_t rows, int64_t row_len, int per_row, int n_levels, int soft, nq_stream_t stream) {
   if (!x || !alpha || !delta || !zp || !y || bad_rows(rows, row_len)) return NQ_ERR_INVALID;
   hipLaunchKernelGGL(adaround_fwd_kernel, row_grid(rows, row_len), dim3(TPB), 0, nq_s(stream), x, alpha, delta, zp, y,
-                     xq, row_len, per_row, (float)(n_levels - 1), soft);
+                     xq, row_len, per_row, (float)(n_levels - 1), soft, blocks_per_row(row_len));
   return nq_launch_status();
 }
 
@@ -391,7 +395,7 @@ int nq_adaround_backward(const float* x, const float* gy, const float* alpha, co
                          float reg_b, nq_stream_t stream) {
   if (!x || !gy || !alpha || !delta || !zp || !dalpha || bad_rows(rows, row_len)) return NQ_ERR_INVALID;
   hipLaunchKernelGGL(adaround_bwd_kernel, row_grid(rows, row_len), dim3(TPB), 0, nq_s(stream), x, gy, alpha, delta, zp,
-                     dalpha, row_len, per_row, (float)(n_levels - 1), reg_weight, reg_b);
+                     dalpha, row_len, per_row, (float)(n_levels - 1), reg_weight, reg_b, blocks_per_row(row_len));
   return nq_launch_status();
 }
 

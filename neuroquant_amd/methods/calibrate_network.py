@@ -66,6 +66,23 @@ def seed_all(seed=903):
     torch.cuda.manual_seed_all(seed)
 
 
+def dist_setup():
+    """Data-parallel launch: under `python -m torch.distributed.run --nproc-per-node N ... -m
+    neuroquant_amd.methods.calibrate_network ...` every rank binds its GPU and joins the RCCL group BEFORE any other GPU call.
+    -> (rank, world, device).  Single process: (0, 1, 'cuda').  NQ_DP_REHEARSAL=1 runs the collective path on a 1-rank
+    group (one GPU)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if 'RANK' not in os.environ or (world == 1 and not os.environ.get('NQ_DP_REHEARSAL')):
+        return 0, 1, 'cuda'
+    import torch.distributed as dist
+    rank, local = int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    return rank, world, f'cuda:{local}'
+
+
 def load_frames(args, cfg, device):
     """-> uint8 (N,3,crop_h,crop_w) on `device`: sorted PNGs, center crop (reference videosets/datasets.py:8-30)."""
     h, w = cfg['crop_h'], cfg['crop_w']
@@ -110,21 +127,28 @@ def evaluate(model, cache: FrameCache, args, cfg):
 
 
 def calibrate(args, cfg):
-    device = 'cuda'
     if not torch.cuda.is_available():
         raise RuntimeError('neuroquant_amd needs an AMD GPU (no CPU path); the reference CPU path lives in oracle/ for tests')
+    # one process per GPU: --batch_size is the GLOBAL batch, each rank takes batch_size/world frames of every batch; all
+    # ranks hold all frames / embeddings / parameters, evaluate identically (replicas are bit-identical), rank 0 logs + saves
+    rank, world, device = dist_setup()
+    if args.batch_size % world:
+        raise ValueError(f'--batch_size {args.batch_size} must divide over {world} ranks')
     frames = load_frames(args, cfg, device)
     cache = FrameCache(frames)
     n = len(cache)
     split = [int(x) for x in args.data_split.split('_')]
     train_ind, args.val_ind_list = data_split(list(range(n)), split, False, 0)
-    train_loader = CacheLoader(cache, train_ind, args.batch_size, seed=args.seed)
+    train_loader = CacheLoader(cache, train_ind, args.batch_size, seed=args.seed, rank=rank, world=world)
 
     model = (HNeRV if args.arch == 'hnerv' else NeRV)(cfg).to(device)
     dec_param = sum(p.numel() for p in model.decoder.parameters()) / 1e6
-    os.makedirs(args.outf, exist_ok=True)
-    setup_logger(os.path.join(args.outf, time.strftime('%Y%m%d_%H%M%S') + '.log'))
-    logging.info(f'Decoder_{round(dec_param, 2)}M')
+    if rank == 0:
+        os.makedirs(args.outf, exist_ok=True)
+        setup_logger(os.path.join(args.outf, time.strftime('%Y%m%d_%H%M%S') + '.log'))
+    else:
+        logging.getLogger().setLevel(logging.WARNING)
+    logging.info(f'Decoder_{round(dec_param, 2)}M' + (f' | data-parallel over {world} GPUs, {args.batch_size // world} frames per GPU' if world > 1 else ''))
     if args.ckpt != 'None':
         logging.info("=> loading checkpoint '{}'".format(args.ckpt))
         model.load_state_dict(torch.load(args.ckpt, map_location='cpu'), strict=False)
@@ -171,7 +195,9 @@ def calibrate(args, cfg):
     res = evaluate(qnn, cache, args, cfg)[0]
     report('Weight quantization w/ opt', res)
     tag = 'CW' if args.channel_wise else 'LW'
-    torch.save(qnn, "{}/{}_W{}_prob{}_{}-init_{}.pth".format(args.outf, args.arch, args.qbits, args.input_prob, args.init, tag))
+    if rank == 0:
+        torch.save(qnn, "{}/{}_W{}_prob{}_{}-init_{}.pth".format(args.outf, args.arch, args.qbits, args.input_prob, args.init, tag))
+    args.qnn = qnn
     return res
 
 
@@ -184,7 +210,12 @@ def main(argv):
                              "network-wise_calib/hadamard-{}_{}-init_batch{}_CW_weight{}_brange{}-{}_warmup{}_lr{}".format(
                                  args.hadamard, args.init, args.batch_size, args.weight, args.b_start, args.b_end,
                                  args.warmup, args.lr))
-    return calibrate(args, cfg)
+    try:
+        return calibrate(args, cfg)
+    finally:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -106,13 +106,15 @@ def uaq_forward(x, delta, zp, n_levels, out=None):
     return y
 
 
-def uaq_backward(x, gy, delta, zp, n_levels):
+def uaq_backward(x, gy, delta, zp, n_levels, want_dx=False):
+    """d(delta) of the UAQ fake-quant; want_dx -> (d(delta), dx) with dx the straight-through gradient w.r.t. x."""
     x, gy, delta, zp = _dev(x), _dev(gy), _dev(delta), _dev(zp)
     rows, rl, per_row = _rows(x, delta)
     dd = torch.empty_like(delta)
-    L.check(L.lib().nq_uaq_backward(_p(x), _p(gy), _p(delta), _p(zp), _p(dd), rows, rl, per_row, n_levels, _stream()),
+    dx = torch.empty_like(x) if want_dx else None
+    L.check(L.lib().nq_uaq_backward(_p(x), _p(gy), _p(delta), _p(zp), _p(dd), _p(dx), rows, rl, per_row, n_levels, _stream()),
             "uaq_backward")
-    return dd
+    return (dd, dx) if want_dx else dd
 
 
 def adaround_init(x, delta_uaq, zp_uaq):
@@ -236,7 +238,11 @@ class _UAQFn(Function):
     @staticmethod
     def backward(ctx, gy):
         x, delta, zp = ctx.saved_tensors
-        # d/dx (straight-through) is never consumed on this path: the FP weight is not optimised
+        # round_ste (quantizer.py:53-57): d/dx = gy inside the clamp range.  Only computed when somebody asks for it (a
+        # trainable quantiser input); the calibration engine never does -- the FP weight is not optimised
+        if ctx.needs_input_grad[0]:
+            dd, dx = uaq_backward(x, gy, delta, zp, ctx.n_levels, want_dx=True)
+            return dx, dd.view_as(delta), None, None
         return None, uaq_backward(x, gy, delta, zp, ctx.n_levels).view_as(delta), None, None
 
 
@@ -252,6 +258,11 @@ class _AdaRoundFn(Function):
     @staticmethod
     def backward(ctx, gy, _gxq):
         x, alpha, delta, zp = ctx.saved_tensors
+        # x enters through floor(x/delta) (quantizer.py:290), whose gradient is zero: None IS the reference's gradient
+        # for x.  d(delta) exists in the reference's graph but no optimiser ever steps it in phase 2 (calib_model.py:
+        # 186-195 collects alpha only); it is not computed here -- ask loudly rather than return silent zeros
+        if ctx.needs_input_grad[2] and os.environ.get("NQ_STRICT_GRADS"):
+            raise NotImplementedError("d(delta) of the AdaRound fake-quant is not built (never stepped by the reference)")
         da = adaround_backward(x, gy, alpha, delta, zp, ctx.n_levels) if ctx.soft else None
         return None, da, None, None, None, None
 
@@ -517,8 +528,24 @@ class _ConvFn(Function):
 # closed under differentiation:  dF = (D(gy,w), Wg(x,gy));  dD = (F(g,w), Wg(g,gy));  dWg = (D(gy,G), F(x,G)).
 # Each is an autograd Function whose backward is built from the other two, so create_graph=True works to any order
 # on the same HIP kernels as the calibration loop (bf16x3 where the grid fills the chip, exact fp32 MFMA otherwise).
+_PRECISION = None   # set_conv_precision() override; None -> NQ_CONV_PRECISION (default 'bf16x3')
+
+
+def set_conv_precision(precision):
+    """'bf16x3' | 'fp32' | None (= environment NQ_CONV_PRECISION, default 'bf16x3'): which MFMA pipe the large
+    convolutions run on from now on.  bench.py / the precision gate switch it between runs of one process."""
+    global _PRECISION
+    if precision not in (None, "fp32", "bf16x3"):
+        raise ValueError(f"unknown conv precision {precision!r}")
+    _PRECISION = precision
+
+
+def get_conv_precision():
+    return _PRECISION or os.environ.get("NQ_CONV_PRECISION", "bf16x3")
+
+
 def _use3(precision):
-    return (precision or os.environ.get("NQ_CONV_PRECISION", "bf16x3")) == "bf16x3"
+    return (precision or get_conv_precision()) == "bf16x3"
 
 
 def _conv_plain(x, w, precision=None):
@@ -643,7 +670,7 @@ class DecoderSpec:
         self.tanh_out = tanh_out
         # 'bf16x3': convolutions whose grid fills the chip run on the BF16 matrix pipe with split fp32 operands
         # (hi*hi + hi*lo + lo*hi, fp32 accumulate; see conv_igemm3_impl.h); 'fp32': exact fp32 MFMA everywhere.
-        self.precision = precision or os.environ.get("NQ_CONV_PRECISION", "bf16x3")
+        self.precision = precision or get_conv_precision()
         if self.precision not in ("fp32", "bf16x3"):
             raise ValueError(f"unknown conv precision {self.precision!r}")
         # NQ_WGRAD_STREAM=1: weight gradients on a second HIP stream, concurrent with the data-gradient chain (measured
@@ -727,7 +754,9 @@ class _DecoderStackFn(Function):
             else:
                 wt, dims, _, _ = weight_layouts(W, need_bwd=False)
             wbk = dims_b = None
-            if l > 0 and not use3_bwd:
+            if (l > 0 and not use3_bwd) or (l == 0 and ctx.needs_input_grad[0]):
+                # layer 0's data-gradient operand is only needed when the embedding itself is trained (FP32 trainer:
+                # the ConvNeXt encoder sits below it, reference regress.py:259-266)
                 _, _, wbk, dims_b = weight_layouts(W, need_bwd=True)
             last = l == n - 1
             if last:
@@ -762,6 +791,7 @@ class _DecoderStackFn(Function):
         spec, metas, n = ctx.spec, ctx.metas, ctx.n
         saved = ctx.saved_tensors
         img, xs, zs = saved[0], saved[1:1 + n], saved[1 + n:]
+        d_emb = None
         g = _dev(g_img, "grad")
         if spec.tanh_out:
             dconv = torch.empty_like(g)
@@ -819,6 +849,8 @@ class _DecoderStackFn(Function):
                 dw, db = wgrad(l, dconv)
             grads[2 * l], grads[2 * l + 1] = dw, db
             if l == 0:
+                if ctx.needs_input_grad[0]:   # d(embedding): plain data gradient through layer 0 (no activation below it)
+                    d_emb, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, EPI_PLAIN, 1)
                 break
             kp, rp, actp = spec.layers[l - 1]
             epi_b, r_b, zp = (EPI_DGRAD_GELU, rp, zs[l]) if actp else (EPI_PLAIN, 1, None)
@@ -839,7 +871,7 @@ class _DecoderStackFn(Function):
         if arena is not None:
             _GRAD_ARENA_HOOK(arena)
             GRAD_ARENA_REDUCED = True
-        return (None, None) + tuple(grads)
+        return (d_emb, None) + tuple(grads)
 
 
 def decoder_stack(emb, spec: DecoderSpec, weights):

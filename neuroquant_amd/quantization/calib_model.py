@@ -130,13 +130,15 @@ class _Layer:
 def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: str = 'hnerv', batch_size: int = 8,
                          iters: int = 20000, weight: float = 0.01, opt_mode: str = 'mse', hadamard: bool = True,
                          b_range: tuple = (20, 2), warmup: float = 0.0, p: float = 2.0, lr: float = 0.0015,
-                         recorder: list = None, max_steps: int = None, step_hook=None):
+                         recorder: list = None, max_steps: int = None, step_hook=None, probe=None):
     """Network-wise calibration, in place (reference calib_model.py:92-240).
 
     gt: any sized iterable of dict batches {'img' (B,3,H,W), 'idx' (B,), 'norm_idx'}; cali_data[idx] feeds the
     decoder.  recorder (optional list) receives (total, round, b, count) per iteration -- this forces one host
     sync per iteration and is meant for parity tests.  max_steps truncates the run and step_hook(done) is called
-    before every iteration (bench.py uses both to time exactly K steps).
+    before every iteration (bench.py uses both to time exactly K steps).  probe(phase, layers, grads) is called after
+    the backward pass and before the optimiser step with phase 'uaq' | 'ada', the engine's per-layer records (L.W.grad /
+    L.b.grad = dL/dW^, dL/db^) and the list of parameter gradients in optimiser order (gradient parity tests).
     """
     if arch not in ('hnerv', 'nerv'):
         raise ValueError
@@ -222,6 +224,8 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                     if count % 500 == 0:
                         logging.info('Total loss:\t{:.4f} (rec:{:.4f}, round:{:.4f})\tb={:.2f}\tcount={}'.format(
                             total, float(rec), rl_f, b, count))
+                if probe is not None:
+                    probe('ada' if ada else 'uaq', layers, grads)
                 opt.step(grads)
                 for L in layers:
                     L.release()

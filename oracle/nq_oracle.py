@@ -212,6 +212,9 @@ class Decoder:
     layers: List[ConvLayer]
     fc_hw: tuple = (1, 1)      # channel->space factors applied to layer-0 output (NeRV.py:49-51)
     out_bias: str = "tanh"
+    # Convolution used by forward(); tests swap it to probe the sensitivity of a calibration trajectory to the fp32
+    # summation order of the convolutions (float64 accumulation, flipped spatial order): tests/golden/make_sensitivity.py
+    conv_fn: object = F.conv2d
 
     @staticmethod
     def from_state_dict(sd: dict, arch: str, dec_strides: Sequence[int], fc_hw=(1, 1), out_bias="tanh") -> "Decoder":
@@ -229,7 +232,7 @@ class Decoder:
         x = emb
         for i, L in enumerate(self.layers):
             W, b = (L.w, L.b) if weights is None else weights[i]
-            x = F.conv2d(x, W, b, stride=1, padding=L.pad)
+            x = self.conv_fn(x, W, b, stride=1, padding=L.pad)
             if i == 0:
                 n, c, h, w = x.shape
                 fh, fw = self.fc_hw
@@ -300,12 +303,14 @@ class QuantStack:
 
 def calibrate(qs: QuantStack, cali_data: torch.Tensor, frames: torch.Tensor, order, iters: int,
               weight: float = 0.01, b_range=(20, 2), warmup: float = 0.2, p: float = 2.0, lr: float = 0.003,
-              max_steps: Optional[int] = None):
+              max_steps: Optional[int] = None, on_step=None, probe=None):
     """model_reconstruction (calib_model.py:92-240) with `gt` replaced by frames + a recorded batch order.
 
     order: int array (n_epochs, batches_per_epoch, B) -- frame indices per iteration.
     Returns the per-iteration log [(total, round, b, count)], counts restarting per phase like the reference.
-    max_steps truncates the run (for timing a bounded sample) without changing the schedule.
+    max_steps truncates the run (for timing a bounded sample) without changing the schedule; on_step(done) is called
+    before every iteration (bench.py stamps the clock there); probe(phase, qs, fq_weights) is called after backward and
+    before the optimiser step with the fake-quantised (W, b) pairs whose .grad hold dL/dW^, dL/db^ (gradient parity tests).
     """
     n_batches = order.shape[1]
     log, done = [], 0
@@ -319,10 +324,19 @@ def calibrate(qs: QuantStack, cali_data: torch.Tensor, frames: torch.Tensor, ord
         count = 0
         for ep in range(ep0, ep0 + epochs):
             for it in range(n_batches):
+                if on_step is not None:
+                    on_step(done)
                 if max_steps is not None and done >= max_steps:
                     return
                 idx = torch.as_tensor(order[ep][it], dtype=torch.int64)
-                out = qs.forward(cali_data[idx])
+                if probe is not None:
+                    fq = qs.fake_quant_weights()
+                    for W_, b_ in fq:
+                        W_.retain_grad()
+                        b_.retain_grad()
+                    out = qs.dec.forward(cali_data[idx], fq)
+                else:
+                    out = qs.forward(cali_data[idx])
                 opt.zero_grad()
                 count += 1
                 rec = lp_loss(out, frames[idx], p)
@@ -333,8 +347,10 @@ def calibrate(qs: QuantStack, cali_data: torch.Tensor, frames: torch.Tensor, ord
                     rl = round_regulariser([L.wa for L in qs.dec.layers], b, weight)
                 total = rl + rec
                 total.backward()
+                if probe is not None:
+                    probe("ada" if round_on else "uaq", qs, fq)
                 opt.step()
-                log.append((float(total), float(rl), float(b), count))
+                log.append((float(total.detach()), float(rl.detach()) if torch.is_tensor(rl) else float(rl), float(b), count))
                 done += 1
         for q in params:
             q.requires_grad_(False)

@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Precision / PSNR gate at the headline size (HNeRV Bunny_1280x640_3M, bits 6 5 4 5 5 6 6, B = 2).
+
+BASELINE.json's metric is "calibration iters/sec + final PSNR vs ref"; the default convolution path is bf16x3 (fp32
+operands split into bf16 hi+lo on the BF16 matrix pipe), so the throughput number is only worth something if that path
+ends at the same PSNR as exact fp32.  This tool establishes it on a TRAINED 3M model ("sensitivity grows
+with PSNR ... repeat on the real model"):
+
+  1. frames: the 8 Bunny-derived fixture frames (tests/golden/frames_320x640.npz) upsampled 2x (nearest) to 640x1280
+     -- real video content, bit-identical on every machine -- or `--frames synthetic` (SURVEY §8d frames);
+  2. FP32 fit of HNeRV-3M (encoder + decoder) with the repo's own trainer path (fused HIP decoder, torch Adam) to a real
+     operating point (>= 30 dB);
+  3. the SAME calibration (same recorded batch order; phase 1 = scales AND phase 2 = AdaRound; reference flow
+     methods/calibrate_network.py:229-298, quantization/calib_model.py:134-226) under exact-fp32 MFMA and under bf16x3
+     -> |dPSNR| must be < 0.02 dB (north-star bar);
+  4. GPU exact-fp32 vs the CPU oracle for `--oracle-iters` iterations (chosen so that int(0.05*iters/len(gt)) >= 1, i.e.
+     phase 1 runs) on the same checkpoint / frames / order -> per-iteration loss agreement and final PSNR.
+
+    python tools/precision_gate.py --train-steps 3000 --iters 2000 --oracle-iters 200 --out gpurun_out/gate.json
+    python tools/precision_gate.py --iters 21000 --frames-n 8 ...        (the full-length schedule)
+"""
+import argparse
+import copy
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from bench import BITS, HNERV_3M  # noqa: E402
+
+FLAGS = dict(weight=0.01, b_range=(20, 2), warmup=0.2, lr=0.003)
+
+
+def bunny_frames_640(dev, n=8):
+    """uint8 (n,3,640,1280): the committed 320x640 Bunny-derived frames, every pixel repeated 2x2 (integer-exact)."""
+    z = np.load(os.path.join(ROOT, "tests", "golden", "frames_320x640.npz"))["frames"][:n]
+    f = torch.from_numpy(z.copy())
+    return f.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3).contiguous().to(dev)
+
+
+def make_order(n, B, iters, seed=903):
+    """(epochs, batches, B) frame indices: one seeded permutation per epoch (shuffle=True, drop_last=True loader,
+    reference calibrate_network.py:162-165), recorded so that every engine replays the same batches."""
+    g = torch.Generator().manual_seed(seed)
+    n_ep = max(int(iters / (n // B)), 1)
+    return torch.stack([torch.randperm(n, generator=g)[: (n // B) * B].view(n // B, B) for _ in range(n_ep)]).numpy()
+
+
+def train_checkpoint(frames_u8, steps, dev, seed=903, lr=1e-3, log=print):
+    """FP32 fit of HNeRV-3M on `frames_u8` through the repo's trainer path (methods/regress.py: fused HIP decoder node,
+    encoder + Adam in PyTorch).  -> (model in eval mode on dev, embeddings (n,16,2,4), FP PSNR)."""
+    from neuroquant_amd import ops
+    from neuroquant_amd.models import HNeRV
+    from neuroquant_amd.utils import CacheLoader, FrameCache
+    torch.manual_seed(seed)
+    model = HNeRV(HNERV_3M).to(dev)
+    cache = FrameCache(frames_u8)
+    n = len(cache)
+    B = 2
+    per_epoch = n // B
+    loader = CacheLoader(cache, list(range(n)), B, seed=seed, epoch_batches=per_epoch)
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    model.train()
+    t0, it = time.time(), 0
+    while it < steps:
+        for sample in loader:
+            if it >= steps:
+                break
+            cur = lr * it / (0.1 * steps) + 1e-6 if it < 0.1 * steps else lr * 0.5 * (1 + math.cos(math.pi * (it - 0.1 * steps) / (0.9 * steps)))
+            for gr in opt.param_groups:
+                gr["lr"] = cur
+            img = sample["img"]
+            out, _, _ = model(img)
+            loss = ops.l2_loss(out, img) / img.shape[1]
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            it += 1
+    torch.cuda.synchronize()
+    model.eval()
+    with torch.no_grad():
+        idx = torch.arange(n, device=dev)
+        emb = torch.cat([model.encode(cache.batch(idx[i:i + 1])) for i in range(n)])
+        psnr = float(torch.cat([ops.frame_psnr(model.decode(emb[i:i + 1])[0], cache.batch(idx[i:i + 1]))
+                                for i in range(n)]).mean())
+    log(f"FP32 fit: {steps} steps in {time.time() - t0:.1f}s, FP PSNR {psnr:.3f} dB")
+    return model, emb, psnr
+
+
+def eval_psnr(qnn, emb, frames, precision="fp32"):
+    """mean per-frame PSNR of the (quantised) model, decoded with the given convolution precision."""
+    from neuroquant_amd import ops
+    prev = ops._PRECISION
+    ops.set_conv_precision(precision)
+    try:
+        with torch.no_grad():
+            return float(torch.cat([ops.frame_psnr(qnn(emb[i:i + 1])[0], frames[i:i + 1])
+                                    for i in range(emb.shape[0])]).double().mean())
+    finally:
+        ops.set_conv_precision(prev)
+
+
+def calibrate_gpu(model, frames_u8, emb, order, iters, precision, record=True, flags=FLAGS, bits=BITS):
+    """One calibration of a deep copy of `model` under `precision`.  -> dict(psnr..., log (iters,4) or None, qnn)."""
+    from neuroquant_amd import ops
+    from neuroquant_amd.quantization import QuantModel, model_reconstruction
+    from neuroquant_amd.utils import CacheLoader, FrameCache
+    frames = frames_u8.float() / 255.0
+    ops.set_conv_precision(precision)
+    try:
+        qnn = QuantModel(copy.deepcopy(model), hadamard=False,
+                         weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
+        qnn.set_bitwidth(bits)
+        qnn.eval()
+        qnn.set_quant_state(True)
+        with torch.no_grad():
+            qnn(emb[:2])       # lazy scale init (calibrate_network.py:235-238)
+        res = {"q_noopt": eval_psnr(qnn, emb, frames)}
+        rec = [] if record else None
+        loader = CacheLoader(FrameCache(frames_u8), list(range(frames_u8.shape[0])), order.shape[2], order=order)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        model_reconstruction(qnn, cali_data=emb, gt=loader, arch="hnerv", batch_size=order.shape[2], iters=iters,
+                             hadamard=False, recorder=rec, **flags)
+        torch.cuda.synchronize()
+        res["seconds"] = time.time() - t0
+        qnn.set_quant_state(True)
+        res["q_opt"] = eval_psnr(qnn, emb, frames)                       # evaluated with exact-fp32 convolutions
+        res["q_opt_eval_bf16x3"] = eval_psnr(qnn, emb, frames, "bf16x3")  # ... and with the default kernels
+        res["iterations"] = len(rec) if rec is not None else None
+        return res, (np.array(rec) if rec else None), qnn
+    finally:
+        ops.set_conv_precision(None)
+
+
+def calibrate_oracle(sd, frames_u8, emb, order, iters, threads, flags=FLAGS, bits=BITS, on_step=None):
+    from oracle import nq_oracle as O
+    torch.set_num_threads(threads)
+    dec = O.Decoder.from_state_dict({k: v for k, v in sd.items() if not k.startswith("encoder")}, "hnerv",
+                                    HNERV_3M["dec_strides"])
+    fr, em = frames_u8.cpu().float() / 255.0, emb.cpu()
+    qs = O.QuantStack(dec, bits, hadamard=False)
+    res = {}
+    with torch.no_grad():
+        res["q_noopt"] = float(O.psnr_per_frame(qs.forward(em), fr).double().mean())
+    t0 = time.time()
+    log = np.array(O.calibrate(qs, em, fr, order, iters, on_step=on_step, **flags))
+    res["seconds"] = time.time() - t0
+    with torch.no_grad():
+        res["q_opt"] = float(O.psnr_per_frame(qs.forward(em), fr).double().mean())
+    res["iterations"] = len(log)
+    return res, log, qs
+
+
+def mask_agreement(qnn_a, qnn_b):
+    same = tot = 0
+    for ma, mb in zip(qnn_a.quant_modules(), qnn_b.quant_modules()):
+        same += int(((ma.weight_quantizer.alpha >= 0) == (mb.weight_quantizer.alpha >= 0)).sum())
+        tot += ma.weight_quantizer.alpha.numel()
+    return same / tot
+
+
+def run(args, log=print):
+    dev = torch.device("cuda", 0)
+    n, B = args.frames_n, 2
+    if args.frames == "bunny":
+        frames_u8 = bunny_frames_640(dev, n)
+    else:
+        from neuroquant_amd.utils import synthetic_frames
+        frames_u8 = synthetic_frames(n, 640, 1280, seed=903, device=dev)
+    n = frames_u8.shape[0]
+    if args.ckpt and os.path.exists(args.ckpt):
+        from neuroquant_amd.models import HNeRV
+        blob = torch.load(args.ckpt, map_location="cpu")
+        model = HNeRV(HNERV_3M)
+        model.load_state_dict(blob["sd"])
+        model = model.to(dev).eval()
+        emb, fp_psnr = blob["emb"].to(dev), blob["fp_psnr"]
+    else:
+        model, emb, fp_psnr = train_checkpoint(frames_u8, args.train_steps, dev, log=log)
+        if args.save_ckpt:
+            os.makedirs(os.path.dirname(os.path.abspath(args.save_ckpt)), exist_ok=True)
+            torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "emb": emb.cpu(), "fp_psnr": fp_psnr},
+                       args.save_ckpt)
+    res = {"config": f"HNeRV Bunny_1280x640_3M, {n} frames ({args.frames}), B={B}, bits {BITS}, iters_w={args.iters}",
+           "fp_psnr": fp_psnr, "train_steps": args.train_steps}
+
+    # ---- fp32 MFMA vs bf16x3, same order, phase 1 + phase 2 ----
+    order = make_order(n, B, args.iters)
+    runs = {}
+    for prec in ("fp32", "bf16x3"):
+        r, lg, qnn = calibrate_gpu(model, frames_u8, emb, order, args.iters, prec, record=args.record)
+        runs[prec] = (r, lg, qnn)
+        res[prec] = r
+        log(f"{prec}: {r['iterations']} iterations in {r['seconds']:.1f}s, PSNR w/o opt {r['q_noopt']:.4f} -> w/ opt {r['q_opt']:.4f} dB")
+    res["dpsnr_fp32_vs_bf16x3_dB"] = abs(res["fp32"]["q_opt"] - res["bf16x3"]["q_opt"])
+    res["mask_agreement_fp32_vs_bf16x3"] = mask_agreement(runs["fp32"][2], runs["bf16x3"][2])
+    if args.record:
+        a, b = runs["fp32"][1], runs["bf16x3"][1]
+        rel = np.abs(a[:, 0] - b[:, 0]) / np.abs(a[:, 0])
+        ep1 = int(0.05 * args.iters / (n // B)) * (n // B)
+        res["loss_rel_diff_fp32_vs_bf16x3"] = {"first3": float(rel[:3].max()), "phase1_max": float(rel[:max(ep1, 1)].max()),
+                                               "max": float(rel.max()), "median": float(np.median(rel)),
+                                               "phase1_iterations": ep1}
+    del runs
+
+    # ---- GPU exact fp32 vs the CPU oracle ----
+    if args.oracle_iters:
+        it_o = args.oracle_iters
+        assert int(0.05 * it_o / (n // B)) >= 1, "choose --oracle-iters so that phase 1 runs (int(0.05*iters/len(gt)) >= 1)"
+        order_o = make_order(n, B, it_o, seed=904)
+        sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        g, glog, _ = calibrate_gpu(model, frames_u8, emb, order_o, it_o, "fp32", record=True)
+        g3, glog3, _ = calibrate_gpu(model, frames_u8, emb, order_o, it_o, "bf16x3", record=True)
+        c, clog, _ = calibrate_oracle(sd, frames_u8, emb, order_o, it_o, args.cpu_threads)
+        rel = np.abs(glog[:, 0] - clog[:, 0]) / np.abs(clog[:, 0])
+        rel3 = np.abs(glog3[:, 0] - clog[:, 0]) / np.abs(clog[:, 0])
+        ep1 = int(0.05 * it_o / (n // B)) * (n // B)
+        res["oracle"] = {"iters_w": it_o, "iterations": int(len(clog)), "phase1_iterations": ep1, "cpu": c, "gpu_fp32": g,
+                         "gpu_bf16x3": g3,
+                         "loss_rel_diff_fp32": {"first3": float(rel[:3].max()), "phase1_max": float(rel[:ep1].max()),
+                                                "max": float(rel.max())},
+                         "loss_rel_diff_bf16x3": {"first3": float(rel3[:3].max()), "phase1_max": float(rel3[:ep1].max()),
+                                                  "max": float(rel3.max())},
+                         "dpsnr_fp32_dB": abs(g["q_opt"] - c["q_opt"]), "dpsnr_bf16x3_dB": abs(g3["q_opt"] - c["q_opt"]),
+                         "cpu_threads": args.cpu_threads}
+        log(f"oracle {it_o} iters: CPU {c['q_opt']:.4f} dB ({c['seconds']:.0f}s), GPU fp32 {g['q_opt']:.4f}, bf16x3 {g3['q_opt']:.4f}; "
+            f"loss rel diff fp32 max {rel.max():.2e}, bf16x3 max {rel3.max():.2e}")
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--train-steps", type=int, default=3000)
+    ap.add_argument("--iters", type=int, default=2000, help="iters_w of the fp32-vs-bf16x3 calibration (21000 = full length)")
+    ap.add_argument("--oracle-iters", type=int, default=200, help="iters_w of the GPU-vs-CPU-oracle calibration; 0 = skip")
+    ap.add_argument("--frames", choices=("bunny", "synthetic"), default="bunny")
+    ap.add_argument("--frames-n", type=int, default=8)
+    ap.add_argument("--cpu-threads", type=int, default=16)
+    ap.add_argument("--no-record", dest="record", action="store_false", help="no per-iteration loss log (no host sync per step)")
+    ap.add_argument("--ckpt", default=None, help="load this checkpoint instead of training")
+    ap.add_argument("--save-ckpt", default=None)
+    ap.add_argument("--out", default=None)
+    args = ap.parse_args()
+    res = run(args)
+    txt = json.dumps(res, indent=1)
+    print(txt)
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        open(args.out, "w").write(txt)
+    ok = res["dpsnr_fp32_vs_bf16x3_dB"] < 0.02 and res["fp_psnr"] >= 30.0
+    if "oracle" in res:
+        ok = ok and res["oracle"]["dpsnr_fp32_dB"] < 0.02 and res["oracle"]["dpsnr_bf16x3_dB"] < 0.02
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()
