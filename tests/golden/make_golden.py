@@ -12,6 +12,7 @@ source or bytecode is copied.
 Fixtures (what each one pins; reference file:line):
   uaq.npz            UniformAffineQuantizer init 'max' + forward + d(delta)   quantizer.py:111-168
   adaround.npz       AdaRoundQuantizer init_alpha / soft+hard forward / grads quantizer.py:259-319
+  zero_channel.npz   the all-zero-output-channel quirk (delta 1e-8 -> fp16 0 -> NaN alpha / NaN forward)  quantizer.py:163-165, 264-265
   roundloss.npz      rounding regulariser value + grad                        calib_model.py:39-47
   tempdecay.json     LinearTempDecay table                                    data_utils.py:24-41
   quantmodule.npz    QuantModule.forward, Hadamard off/on (on = FWHT stub)    quant_layer.py:24-89
@@ -180,6 +181,32 @@ def gen_adaround():
         out[f"b{nb}_delta"], out[f"b{nb}_zp"], out[f"b{nb}_alpha0"] = npy(ab.delta), npy(ab.zero_point), npy(ab.alpha)
         out[f"b{nb}_ysoft"], out[f"b{nb}_go"], out[f"b{nb}_dalpha"] = npy(yb), npy(gb), npy(ab.alpha.grad)
     save("adaround.npz", **out)
+
+
+# ----------------------------------------------------------------------------- all-zero output channel
+def gen_zero_channel():
+    """an all-zero output channel gets delta = 1e-8 from the 'max' init (quantizer.py:163-165), which the
+    fp16 round trip of AdaRoundQuantizer.__init__ (quantizer.py:264-265) flushes to 0 -> x/delta = 0/0 -> alpha = NaN and
+    every forward of that channel is NaN in the reference.  Recorded here exactly as the reference produces it."""
+    g = torch.Generator().manual_seed(12)
+    w = torch.randn(4, 5, 3, 3, generator=g) * 0.3
+    w[1] = 0.0
+    q = UniformAffineQuantizer(n_bits=8, channel_wise=True, scale_method="max")
+    q.bitwidth_refactor(4)
+    y_uaq = q(w)
+    out = {"x": npy(w), "uaq_delta": npy(q.delta), "uaq_zp": npy(q.zero_point), "y_uaq": npy(y_uaq)}
+    a = AdaRoundQuantizer(uaq=q, round_mode="learned_hard_sigmoid", weight_tensor=w)
+    out["delta"], out["zp"], out["alpha0"] = npy(a.delta), npy(a.zero_point), npy(a.alpha)
+    a.soft_targets = True
+    ys = a(w)
+    go = torch.randn(w.shape, generator=g)
+    (ys * go).sum().backward()
+    out["ysoft"], out["go"], out["dalpha"] = npy(ys), npy(go), npy(a.alpha.grad)
+    a.soft_targets = False
+    out["yhard"] = npy(a(w))
+    print("  zero channel: uaq delta", out["uaq_delta"].ravel(), "-> fp16 delta", out["delta"].ravel(),
+          "| NaN alpha rows", np.isnan(out["alpha0"]).reshape(4, -1).all(1), "| NaN ysoft rows", np.isnan(out["ysoft"]).reshape(4, -1).all(1))
+    save("zero_channel.npz", **out)
 
 
 # ----------------------------------------------------------------------------- round loss
@@ -550,6 +577,7 @@ def gen_omega():
 GENS = {
     "uaq": gen_uaq,
     "adaround": gen_adaround,
+    "zero_channel": gen_zero_channel,
     "roundloss": gen_roundloss,
     "tempdecay": gen_tempdecay,
     "quantmodule": gen_quantmodule,

