@@ -117,6 +117,18 @@ int nq_adaround_backward_multi(const nq_ada_seg* segs, int nseg, float reg_b, nq
 int nq_adam_step_multi(const nq_adam_seg* segs, int nseg, float step_size, float beta1, float beta2, float eps,
                        float bc2_sqrt, nq_stream_t stream);
 
+/* ---- captured iterations (hipGraph): what changes from one calibration iteration to the next is the batch (frame
+ * indices), the temperature b / regulariser gate (LinearTempDecay + warm-up, calib_model.py:62-81) and Adam's two bias
+ * corrections.  The host writes them for a whole epoch into device tables once; nq_step_prologue copies row *step into
+ * fixed slots (cur_idx: B int64 frame indices; cur_scal: nscal floats) and increments *step, and the _dyn variants read
+ * their scalars from cur_scal = {reg_b, regulariser gate (0 or 1), lr/(1-beta1^t), sqrt(1-beta2^t)} instead of from
+ * host arguments -- same values, same arithmetic, so a replayed iteration is bit-identical to an eagerly launched one. */
+int nq_step_prologue(const int64_t* order, const float* scal, int* step, int64_t* cur_idx, float* cur_scal, int B, int nscal,
+                     nq_stream_t stream);
+int nq_adaround_backward_multi_dyn(const nq_ada_seg* segs, int nseg, const float* dyn, nq_stream_t stream);
+int nq_adam_step_multi_dyn(const nq_adam_seg* segs, int nseg, const float* dyn, float beta1, float beta2, float eps,
+                           nq_stream_t stream);
+
 /* Orthonormal Walsh-Hadamard transform along the middle axis (hadamard_along_channel_weight,
  * quant_layer.py:16-22, with the zero-padding of :45-49 and the slice of :71 folded in):
  * x is [outer][n_in][inner] (read as zero for index >= n_in), y is [outer][n_out][inner], transform

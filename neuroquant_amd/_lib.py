@@ -56,6 +56,9 @@ def _load():
     sig("nq_adaround_forward_multi", I, POINTER(AdaSeg), I, P)
     sig("nq_adaround_backward_multi", I, POINTER(AdaSeg), I, F, P)
     sig("nq_adam_step_multi", I, POINTER(AdamSeg), I, F, F, F, F, F, P)
+    sig("nq_step_prologue", I, P, P, P, P, P, I, I, P)
+    sig("nq_adaround_backward_multi_dyn", I, POINTER(AdaSeg), I, P, P)
+    sig("nq_adam_step_multi_dyn", I, POINTER(AdamSeg), I, P, F, F, F, P)
     sig("nq_reduce_ws_floats", L, L)
     sig("nq_round_loss", I, P, L, F, F, P, P, I, P)
     sig("nq_round_loss_backward", I, P, L, F, F, P, P, I, P)
@@ -88,7 +91,7 @@ def _load():
 EXPORTS = (
     "nq_abi_version", "nq_error_string", "nq_scale_init_max", "nq_uaq_forward", "nq_uaq_backward",
     "nq_adaround_init", "nq_adaround_forward", "nq_adaround_backward", "nq_reduce_ws_floats", "nq_round_loss", "nq_round_loss_backward",
-    "nq_adam_step", "nq_adaround_forward_multi", "nq_adaround_backward_multi", "nq_adam_step_multi", "nq_fwht", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
+    "nq_adam_step", "nq_adaround_forward_multi", "nq_adaround_backward_multi", "nq_adam_step_multi", "nq_step_prologue", "nq_adaround_backward_multi_dyn", "nq_adam_step_multi_dyn", "nq_fwht", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
     "nq_conv3_supported", "nq_conv3_weight_bytes", "nq_weight_layout3", "nq_weight_layout3_multi", "nq_conv_forward3_ws_floats", "nq_conv_forward3",
     "nq_conv_wgrad3_supported", "nq_conv_wgrad3_ws_floats", "nq_conv_wgrad3",
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",

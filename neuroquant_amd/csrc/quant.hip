@@ -80,7 +80,9 @@ __global__ __launch_bounds__(TPB) void uaq_bwd_kernel(const float* __restrict__ 
     float inside = (xi >= 0.f && xi <= qmax) ? 1.f : 0.f;
     const float g = gy[base + i];
     acc += g * ((xq - z) - inside * u);
-    if (dx) dx[base + i] = g * inside;   // round_ste: straight-through inside the clamp range (quantizer.py:53-57, 118)
+    // round_ste (quantizer.py:53-57, 117-119): autograd multiplies by delta (dequantisation), masks by the clamp and
+    // divides by delta again (x/delta): (g*d)/d, not g, in fp32
+    if (dx) dx[base + i] = inside != 0.f ? (g * d) / d : 0.f;
   }
   float s = nq_block_sum(acc, red);
   if (threadIdx.x == 0) ddelta[row] = s;
@@ -271,6 +273,7 @@ struct AdaMulti {
   int blk0[MAXSEG + 1];
   int nseg;
   float reg_b;
+  const float* dyn;  // optional device scalars of the current step (nq_step_prologue): [0] = reg_b, [1] = regulariser gate
 };
 struct AdamSegD {
   float* p;
@@ -303,7 +306,9 @@ __global__ __launch_bounds__(TPB) void adaround_multi_kernel(AdaMulti t) {
       const int64_t row = sg.per_row ? i / sg.row_len : 0;
       const float d = sg.delta[row], z = sg.zp[row];
       if (BWD) {
-        sg.out[i] = ada_bwd_elem(sg.x[i], sg.gy[i], sg.alpha[i], d, z, sg.qmax, sg.reg_weight, t.reg_b);
+        const float rb = t.dyn ? t.dyn[0] : t.reg_b;
+        const float rw = t.dyn ? sg.reg_weight * t.dyn[1] : sg.reg_weight;   // gate is exactly 0 or 1
+        sg.out[i] = ada_bwd_elem(sg.x[i], sg.gy[i], sg.alpha[i], d, z, sg.qmax, rw, rb);
       } else {
         float xq;
         sg.out[i] = ada_fwd_elem(sg.x[i], sg.alpha[i], d, z, sg.qmax, sg.soft, xq);
@@ -313,7 +318,11 @@ __global__ __launch_bounds__(TPB) void adaround_multi_kernel(AdaMulti t) {
 }
 
 __global__ __launch_bounds__(TPB) void adam_multi_kernel(AdamMulti t, float step_size, float beta1, float beta2, float eps,
-                                                         float bc2_sqrt) {
+                                                         float bc2_sqrt, const float* __restrict__ dyn) {
+  if (dyn) {  // per-step scalars from device memory (graph replays): [2] = lr/(1-beta1^t), [3] = sqrt(1-beta2^t)
+    step_size = dyn[2];
+    bc2_sqrt = dyn[3];
+  }
   const int k = find_seg(t, blockIdx.x);
   const AdamSegD& sg = t.s[k];
   int64_t i = (int64_t)(blockIdx.x - t.blk0[k]) * (TPB * EPT) + threadIdx.x;
@@ -426,12 +435,30 @@ int nq_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
   return nq_launch_status();
 }
 
-static int ada_multi(const nq_ada_seg* segs, int nseg, float reg_b, bool bwd, nq_stream_t stream) {
+// One block: copies row `*step` of the per-step tables into the fixed "current step" slots every other kernel of the
+// iteration reads, then advances the counter -- the only thing that changes between two replays of a captured iteration.
+__global__ __launch_bounds__(256) void step_prologue_kernel(const int64_t* __restrict__ order, const float* __restrict__ scal,
+                                                            int* __restrict__ step, int64_t* __restrict__ cur_idx,
+                                                            float* __restrict__ cur_scal, int B, int nscal) {
+  const int s = *step;
+  const int t = threadIdx.x;
+  int64_t vi = 0;
+  float vs = 0.f;
+  if (t < B) vi = order[(int64_t)s * B + t];
+  if (t < nscal) vs = scal[(int64_t)s * nscal + t];
+  __syncthreads();   // every thread has read *step before it is advanced
+  if (t < B) cur_idx[t] = vi;
+  if (t < nscal) cur_scal[t] = vs;
+  if (t == 0) *step = s + 1;
+}
+
+static int ada_multi(const nq_ada_seg* segs, int nseg, float reg_b, const float* dyn, bool bwd, nq_stream_t stream) {
   if (!segs || nseg <= 0) return NQ_ERR_INVALID;
   for (int base = 0; base < nseg; base += MAXSEG) {
     AdaMulti t;
     t.nseg = (nseg - base < MAXSEG) ? nseg - base : MAXSEG;
     t.reg_b = reg_b;
+    t.dyn = dyn;
     int blocks = 0;
     for (int k = 0; k < t.nseg; ++k) {
       const nq_ada_seg& h = segs[base + k];
@@ -455,15 +482,41 @@ static int ada_multi(const nq_ada_seg* segs, int nseg, float reg_b, bool bwd, nq
 }
 
 int nq_adaround_forward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream) {
-  return ada_multi(segs, nseg, 0.f, false, stream);
+  return ada_multi(segs, nseg, 0.f, nullptr, false, stream);
 }
 
 int nq_adaround_backward_multi(const nq_ada_seg* segs, int nseg, float reg_b, nq_stream_t stream) {
-  return ada_multi(segs, nseg, reg_b, true, stream);
+  return ada_multi(segs, nseg, reg_b, nullptr, true, stream);
 }
+
+int nq_adaround_backward_multi_dyn(const nq_ada_seg* segs, int nseg, const float* dyn, nq_stream_t stream) {
+  if (!dyn) return NQ_ERR_INVALID;
+  return ada_multi(segs, nseg, 0.f, dyn, true, stream);
+}
+
+int nq_step_prologue(const int64_t* order, const float* scal, int* step, int64_t* cur_idx, float* cur_scal, int B, int nscal,
+                     nq_stream_t stream) {
+  if (!order || !scal || !step || !cur_idx || !cur_scal || B <= 0 || B > 256 || nscal <= 0 || nscal > 256) return NQ_ERR_INVALID;
+  hipLaunchKernelGGL(step_prologue_kernel, dim3(1), dim3(256), 0, nq_s(stream), order, scal, step, cur_idx, cur_scal, B, nscal);
+  return nq_launch_status();
+}
+
+static int adam_multi(const nq_adam_seg* segs, int nseg, float step_size, float beta1, float beta2, float eps, float bc2_sqrt,
+                      const float* dyn, nq_stream_t stream);
 
 int nq_adam_step_multi(const nq_adam_seg* segs, int nseg, float step_size, float beta1, float beta2, float eps,
                        float bc2_sqrt, nq_stream_t stream) {
+  return adam_multi(segs, nseg, step_size, beta1, beta2, eps, bc2_sqrt, nullptr, stream);
+}
+
+int nq_adam_step_multi_dyn(const nq_adam_seg* segs, int nseg, const float* dyn, float beta1, float beta2, float eps,
+                           nq_stream_t stream) {
+  if (!dyn) return NQ_ERR_INVALID;
+  return adam_multi(segs, nseg, 0.f, beta1, beta2, eps, 1.f, dyn, stream);
+}
+
+static int adam_multi(const nq_adam_seg* segs, int nseg, float step_size, float beta1, float beta2, float eps, float bc2_sqrt,
+                      const float* dyn, nq_stream_t stream) {
   if (!segs || nseg <= 0) return NQ_ERR_INVALID;
   for (int base = 0; base < nseg; base += MAXSEG) {
     AdamMulti t;
@@ -478,7 +531,7 @@ int nq_adam_step_multi(const nq_adam_seg* segs, int nseg, float step_size, float
     }
     t.blk0[t.nseg] = blocks;
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(TPB), 0, nq_s(stream), t, step_size, beta1, beta2,
-                       eps, bc2_sqrt);
+                       eps, bc2_sqrt, dyn);
   }
   return nq_launch_status();
 }

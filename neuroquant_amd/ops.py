@@ -46,6 +46,11 @@ def profile_stop():
     return {k: (len(v), sum(s.elapsed_time(e) for s, e in v)) for k, v in (prof or {}).items()}
 
 
+def profiling_active():
+    """True while per-launch HIP events are being recorded (such steps are launched eagerly, never replayed from a graph)."""
+    return _PROF is not None and _PROF_ON
+
+
 def _timed(key, fn):
     if _PROF is None or not _PROF_ON:
         return fn()
@@ -181,9 +186,16 @@ def adaround_forward_multi(items):
     return outs
 
 
-def adaround_backward_multi(items, reg_b=0.0):
+def step_prologue(order_tab, scal_tab, step_ctr, cur_idx, cur_scal):
+    """nq_step_prologue: cur_idx <- order_tab[*step], cur_scal <- scal_tab[*step], *step += 1 (captured iterations)."""
+    L.check(L.lib().nq_step_prologue(_p(order_tab), _p(scal_tab), _p(step_ctr), _p(cur_idx), _p(cur_scal), cur_idx.numel(),
+                                     cur_scal.numel(), _stream()), "step_prologue")
+
+
+def adaround_backward_multi(items, reg_b=0.0, dyn=None):
     """items: [(x, gy, alpha, delta, zp, n_levels, reg_weight)] -> [d(alpha)] (+ regulariser gradient where
-    reg_weight != 0), ONE launch."""
+    reg_weight != 0), ONE launch.  dyn (device floats {reg_b, gate, ...} of the current step) replaces the host reg_b and
+    gates reg_weight (captured iterations; same arithmetic)."""
     segs = (L.AdaSeg * len(items))()
     outs = []
     for sg, (x, gy, alpha, delta, zp, n_levels, reg_weight) in zip(segs, items):
@@ -193,7 +205,10 @@ def adaround_backward_multi(items, reg_b=0.0):
         outs.append(da)
         sg.x, sg.gy, sg.alpha, sg.delta, sg.zp, sg.out = _p(x), _p(gy), _p(alpha), _p(delta), _p(zp), _p(da)
         sg.rows, sg.row_len, sg.per_row, sg.n_levels, sg.soft, sg.reg_weight = rows, rl, per_row, n_levels, 1, float(reg_weight)
-    L.check(L.lib().nq_adaround_backward_multi(segs, len(items), float(reg_b), _stream()), "adaround_backward_multi")
+    if dyn is not None:
+        L.check(L.lib().nq_adaround_backward_multi_dyn(segs, len(items), _p(dyn), _stream()), "adaround_backward_multi_dyn")
+    else:
+        L.check(L.lib().nq_adaround_backward_multi(segs, len(items), float(reg_b), _stream()), "adaround_backward_multi")
     return outs
 
 
@@ -211,7 +226,12 @@ class FusedAdam:
         for p in self.params:
             p.grad = None
 
-    def step(self, grads=None, beta1=0.9, beta2=0.999, eps=1e-8):
+    def scalars(self, t, beta1=0.9, beta2=0.999):
+        """(lr/(1-beta1^t), sqrt(1-beta2^t)) of step t, as the eager path passes them (host doubles -> fp32)."""
+        return self.lr / (1 - beta1 ** t), (1 - beta2 ** t) ** 0.5
+
+    def step(self, grads=None, beta1=0.9, beta2=0.999, eps=1e-8, dyn=None):
+        """dyn: device floats whose [2], [3] hold scalars(t) of this step (captured iterations)."""
         self.t += 1
         todo = [(p, (p.grad if grads is None else grads[i]), self.m[i], self.v[i]) for i, p in enumerate(self.params)]
         todo = [t for t in todo if t[1] is not None]
@@ -223,6 +243,9 @@ class FusedAdam:
             g = _dev(g).contiguous()
             keep.append(g)
             sg.p, sg.g, sg.m, sg.v, sg.n = _p(p.data), _p(g), _p(m), _p(v), p.numel()
+        if dyn is not None:
+            L.check(L.lib().nq_adam_step_multi_dyn(segs, len(todo), _p(dyn), beta1, beta2, eps, _stream()), "adam_step_multi_dyn")
+            return
         bc1, bc2 = 1 - beta1 ** self.t, 1 - beta2 ** self.t
         L.check(L.lib().nq_adam_step_multi(segs, len(todo), self.lr / bc1, beta1, beta2, eps, bc2 ** 0.5, _stream()),
                 "adam_step_multi")

@@ -161,74 +161,144 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
         import torch.distributed as dist
         ops.set_grad_arena_hook(lambda arena: dist.all_reduce(arena, op=dist.ReduceOp.AVG))
 
+    # Captured iterations (hipGraph): when `gt` can hand over a whole epoch of frame indices
+    # (utils.CacheLoader.epoch_indices) the iteration is captured ONCE per phase with torch.cuda.graph and replayed: the
+    # ~50 launches + ~60 allocations + the autograd walk of one iteration become one graph launch.  What changes between
+    # iterations -- frame indices, temperature / regulariser gate, Adam's bias corrections -- sits in per-epoch device
+    # tables; nq_step_prologue copies the current row into fixed slots that the kernels read (same values and arithmetic
+    # as the host-argument path: replays are bit-identical to eager launches, tested).  Iterations that log (every 500,
+    # the reference's float() sync), that are HIP-event profiled, or the first three of a phase run eagerly through the
+    # SAME body.  Off for: recorder / probe (tests that inspect every iteration), data-parallel runs (the in-place RCCL
+    # all-reduce sits in the middle of the backward pass), generic `gt` iterables, NQ_GRAPH=0.
+    use_graph = (os.environ.get("NQ_GRAPH", "1") != "0" and device.type == 'cuda' and not dp and recorder is None
+                 and probe is None and hasattr(gt, 'epoch_indices') and hasattr(gt, 'cache'))
+
     def run(epochs, params, opt_lr, max_count, ada):
         nonlocal done
         opt = ops.FusedAdam(params, lr=opt_lr)
         loss_start = max_count * warmup
         temp = LinearTempDecay(max_count, rel_start_decay=warmup, start_b=b_range[0], end_b=b_range[1])
         count = 0
+
+        def sched(c):
+            """(b, regulariser on) of the iteration with counter c (calib_model.py:62, 76-81)."""
+            b = temp(c)
+            reg_on = ada and not (c < loss_start)
+            return (b if reg_on else 0), reg_on
+
+        def body(get_batch, b, reg_on, dyn, want_log):
+            """One iteration.  dyn = None: scalars travel as host arguments (b, reg_on, Adam's t); else they are read from
+            the device slots `dyn` = {b, gate, lr/(1-beta1^t), sqrt(1-beta2^t)} filled by nq_step_prologue."""
+            img, inputs = get_batch()
+            if ada:   # all 14 fake-quantised tensors in one launch
+                fq = ops.adaround_forward_multi(
+                    [it for L in layers for it in L.ada_items()])
+                for i, L in enumerate(layers):
+                    L._finish(fq[2 * i], fq[2 * i + 1])
+            else:
+                for L in layers:
+                    L.forward_uaq()
+            ops.GRAD_ARENA_REDUCED = False
+            img_out, _, _ = model(inputs)
+            rec, dimg = ops.l2_loss_and_grad(img_out, img)   # lp_loss p=2 (quantizer.py:66-71) and its gradient
+            img_out.backward(dimg)
+            if dp and not ops.GRAD_ARENA_REDUCED:
+                # generic path (decoder not fused into one node): flatten, all-reduce, un-flatten (SURVEY §8e)
+                allreduce_mean_([t.grad for L in layers for t in (L.W, L.b)])
+            grads = []
+            if ada:   # d(alpha) of all 14 tensors (+ regulariser gradient on the weights) in one launch
+                items = []
+                for L in layers:
+                    gW, gb = L.grads()
+                    wq, bq = L.m.weight_quantizer, L.m.bias_quantizer
+                    # with dyn the regulariser weight is always passed and gated on the device by dyn[1]
+                    items.append((L.src, gW, wq.alpha.data, wq.delta.data, wq.zero_point, wq.n_levels,
+                                  weight if (reg_on or dyn is not None) else 0.0))
+                    items.append((L.bias, gb, bq.alpha.data, bq.delta.data, bq.zero_point, bq.n_levels, 0.0))
+                grads = ops.adaround_backward_multi(items, b, dyn=dyn)
+            else:
+                for L in layers:
+                    gW, gb = L.grads()
+                    wq, bq = L.m.weight_quantizer, L.m.bias_quantizer
+                    grads.append(ops.uaq_backward(L.src, gW, wq.delta.data, wq.zero_point, wq.n_levels))
+                    grads.append(ops.uaq_backward(L.bias, gb, bq.delta.data, bq.zero_point, bq.n_levels))
+            if want_log:
+                rl = torch.zeros((), device=device)
+                if reg_on:
+                    for L in layers:
+                        ops.round_loss(L.m.weight_quantizer.alpha.data, b, weight, out=rl, accumulate=True)
+                total, rl_f = float(rec) + float(rl), float(rl)
+                if recorder is not None:
+                    recorder.append((total, rl_f, float(b), count))
+                if count % 500 == 0:
+                    logging.info('Total loss:\t{:.4f} (rec:{:.4f}, round:{:.4f})\tb={:.2f}\tcount={}'.format(
+                        total, float(rec), rl_f, b, count))
+            if probe is not None:
+                probe('ada' if ada else 'uaq', layers, grads)
+            opt.step(grads, dyn=dyn)
+            for L in layers:
+                L.release()
+
+        if not use_graph:
+            for _ in range(epochs):
+                model.train()
+                for sample in gt:
+                    if step_hook is not None:
+                        step_hook(done)
+                    if max_steps is not None and done >= max_steps:
+                        return
+                    count += 1
+                    b, reg_on = sched(count)
+                    img = sample['img'].to(device, non_blocking=True)
+                    inputs = cali_data[sample['idx'].to(device, non_blocking=True)]
+                    body(lambda: (img, inputs), b, reg_on, None, recorder is not None or count % 500 == 0)
+                    done += 1
+            return
+
+        st = None       # static device state of this phase's captured iteration
+        graph, warm = None, 0
         for _ in range(epochs):
             model.train()
-            for sample in gt:
+            idx_tab = gt.epoch_indices()                     # (batches, frames per batch on this rank), device int64
+            nb, per = idx_tab.shape
+            if st is None or st['order'].shape[0] < nb or st['cur_idx'].numel() != per:
+                st = dict(order=torch.zeros((nb, per), device=device, dtype=torch.int64),
+                          scal=torch.zeros((nb, 4), device=device, dtype=torch.float32),
+                          step=torch.zeros((), device=device, dtype=torch.int32),
+                          cur_idx=torch.zeros(per, device=device, dtype=torch.int64),
+                          cur_scal=torch.zeros(4, device=device, dtype=torch.float32))
+                graph, warm = None, 0
+            rows = []
+            for c in range(count + 1, count + nb + 1):
+                b, reg_on = sched(c)
+                rows.append((float(b), 1.0 if reg_on else 0.0) + opt.scalars(opt.t + (c - count)))
+            st['scal'][:nb].copy_(torch.tensor(rows, dtype=torch.float32), non_blocking=True)
+            st['order'][:nb].copy_(idx_tab)
+            st['step'].zero_()
+
+            def static_batch():
+                ops.step_prologue(st['order'], st['scal'], st['step'], st['cur_idx'], st['cur_scal'])
+                return gt.cache.batch(st['cur_idx']), cali_data.index_select(0, st['cur_idx'])
+
+            for i in range(nb):
                 if step_hook is not None:
                     step_hook(done)
                 if max_steps is not None and done >= max_steps:
                     return
-                img = sample['img'].to(device, non_blocking=True)
-                inputs = cali_data[sample['idx'].to(device, non_blocking=True)]
                 count += 1
-                b = temp(count)
-                reg_on = ada and not (count < loss_start)
-                if not reg_on:
-                    b = 0
-                if ada:   # all 14 fake-quantised tensors in one launch
-                    fq = ops.adaround_forward_multi(
-                        [it for L in layers for it in L.ada_items()])
-                    for i, L in enumerate(layers):
-                        L._finish(fq[2 * i], fq[2 * i + 1])
+                b, reg_on = sched(count)
+                want_log = count % 500 == 0
+                if want_log or warm < 3 or ops.profiling_active():
+                    body(static_batch, b, reg_on, st['cur_scal'], want_log)
+                    warm += 1
+                elif graph is None:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        body(static_batch, b, reg_on, st['cur_scal'], False)   # recorded, not executed (opt.t advanced)
+                    graph.replay()
                 else:
-                    for L in layers:
-                        L.forward_uaq()
-                ops.GRAD_ARENA_REDUCED = False
-                img_out, _, _ = model(inputs)
-                rec, dimg = ops.l2_loss_and_grad(img_out, img)   # lp_loss p=2 (quantizer.py:66-71) and its gradient
-                img_out.backward(dimg)
-                if dp and not ops.GRAD_ARENA_REDUCED:
-                    # generic path (decoder not fused into one node): flatten, all-reduce, un-flatten
-                    allreduce_mean_([t.grad for L in layers for t in (L.W, L.b)])
-                grads = []
-                if ada:   # d(alpha) of all 14 tensors (+ regulariser gradient on the weights) in one launch
-                    items = []
-                    for L in layers:
-                        gW, gb = L.grads()
-                        wq, bq = L.m.weight_quantizer, L.m.bias_quantizer
-                        items.append((L.src, gW, wq.alpha.data, wq.delta.data, wq.zero_point, wq.n_levels,
-                                      weight if reg_on else 0.0))
-                        items.append((L.bias, gb, bq.alpha.data, bq.delta.data, bq.zero_point, bq.n_levels, 0.0))
-                    grads = ops.adaround_backward_multi(items, b)
-                else:
-                    for L in layers:
-                        gW, gb = L.grads()
-                        wq, bq = L.m.weight_quantizer, L.m.bias_quantizer
-                        grads.append(ops.uaq_backward(L.src, gW, wq.delta.data, wq.zero_point, wq.n_levels))
-                        grads.append(ops.uaq_backward(L.bias, gb, bq.delta.data, bq.zero_point, bq.n_levels))
-                want_log = recorder is not None or count % 500 == 0
-                if want_log:
-                    rl = torch.zeros((), device=device)
-                    if reg_on:
-                        for L in layers:
-                            ops.round_loss(L.m.weight_quantizer.alpha.data, b, weight, out=rl, accumulate=True)
-                    total, rl_f = float(rec) + float(rl), float(rl)
-                    if recorder is not None:
-                        recorder.append((total, rl_f, float(b), count))
-                    if count % 500 == 0:
-                        logging.info('Total loss:\t{:.4f} (rec:{:.4f}, round:{:.4f})\tb={:.2f}\tcount={}'.format(
-                            total, float(rec), rl_f, b, count))
-                if probe is not None:
-                    probe('ada' if ada else 'uaq', layers, grads)
-                opt.step(grads)
-                for L in layers:
-                    L.release()
+                    graph.replay()
+                    opt.t += 1
                 done += 1
 
     # ---- phase 1: scales (calib_model.py:119-165; lr and max_count are hard-coded there) ----

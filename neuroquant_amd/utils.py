@@ -120,7 +120,9 @@ class CacheLoader:
         perm = torch.randperm(len(self.indices), generator=self.gen)
         return torch.tensor(self.indices)[perm][: per_pass * self.bs].view(per_pass, self.bs)
 
-    def __iter__(self):
+    def epoch_indices(self):
+        """This rank's frame indices of the NEXT epoch, (batches, batch_size/world) int64 on the cache's device; advances
+        the epoch exactly like one pass of __iter__ (the calibration engine replays captured iterations from this table)."""
         if self.order is None:
             sel = self._one_pass()
             while self.epoch_batches and sel.shape[0] < self.epoch_batches:
@@ -133,7 +135,10 @@ class CacheLoader:
         dev = self.cache.frames.device
         # this rank's slice of every batch goes to the device ONCE per epoch: a per-batch pageable H2D copy would
         # block the host on the stream every iteration
-        mine = sel[:, self.rank * per:(self.rank + 1) * per].contiguous().to(dev)
+        return sel[:, self.rank * per:(self.rank + 1) * per].contiguous().to(dev)
+
+    def __iter__(self):
+        mine = self.epoch_indices()
         norm = mine.float() / self.n_total           # once per epoch; the per-batch rows are views
         for i in range(mine.shape[0]):
             idx = mine[i]

@@ -590,6 +590,41 @@ def test_calibration_trajectory_nerv_hadamard(golden, prec):
     _check_traj("nerv_had", z, qnn, log, psnr1, True)
 
 
+def test_captured_iterations_equal_eager(golden, monkeypatch):
+    """hipGraph replay of the calibration iteration (model_reconstruction with a CacheLoader) vs the eager launches
+    (NQ_GRAPH=0): every scale, rounding variable and Adam moment identical bit for bit after 4 phase-1 + 236 phase-2
+    iterations (warm-up boundary at count 48 inside the run, so the regulariser gate switches inside replays)."""
+    from neuroquant_amd.quantization import QuantModel, model_reconstruction
+    from neuroquant_amd.utils import CacheLoader, FrameCache
+    z = golden("traj_hnerv.npz")
+    frames_u8 = T(golden("frames_320x640.npz")["frames"]).to(DEV)
+    emb = G(z["emb"])
+    order = np.concatenate([z["order"]] * 2)[:60]
+
+    def run(graph):
+        monkeypatch.setenv("NQ_GRAPH", "1" if graph else "0")
+        qnn = QuantModel(_build("hnerv", state_dict_from_npz(z, "sd:")), hadamard=False,
+                         weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
+        qnn.set_bitwidth(BITS); qnn.eval(); qnn.set_quant_state(True)
+        with torch.no_grad():
+            qnn(emb[:2])
+        seen = []
+        loader = CacheLoader(FrameCache(frames_u8), list(range(8)), 2, order=order)
+        model_reconstruction(qnn, cali_data=emb, gt=loader, arch="hnerv", batch_size=2, iters=240, weight=0.01,
+                             hadamard=False, b_range=(20, 2), warmup=0.2, lr=0.003, step_hook=seen.append)
+        out = []
+        for m in qnn.quant_modules():
+            out += [m.weight_quantizer.alpha.detach().clone(), m.bias_quantizer.alpha.detach().clone(),
+                    m.weight_quantizer.delta.detach().clone(), m.bias_quantizer.delta.detach().clone()]
+        return out, seen
+
+    eager, seen_e = run(False)
+    graphed, seen_g = run(True)
+    assert seen_e == seen_g == list(range(240))
+    for a, b in zip(eager, graphed):
+        assert torch.equal(a, b)
+
+
 def test_generic_autograd_path_matches_engine(golden):
     """LossFunction + quantiser modules (generic autograd) == the explicit schedule of model_reconstruction."""
     from neuroquant_amd.quantization import QuantModel, LossFunction, AdaRoundQuantizer
