@@ -10,8 +10,8 @@ int nq_conv_igemm3_k5(const float*, const void*, const float*, float*, float*, c
 int nq_conv_splitk_finish(const float*, const float*, float*, float*, const float*, int, int, int, int, int, int, int, hipStream_t);
 int nq_conv3_nst_k3();
 int nq_conv3_nst_k5();
-int nq_conv_wgrad3_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, hipStream_t);
-int nq_conv_wgrad3_k5(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+int nq_conv_wgrad3_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+int nq_conv_wgrad3_k5(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 }
 
 namespace {
@@ -125,8 +125,13 @@ inline Fwd3Plan plan_fwd3(int B, int Cin, int H, int W, int Cout) {
 }
 
 struct Wg3Plan {
-  int mi, ni, co_pad, n_pad, nsplit;
+  int mi, ni, co_pad, n_pad, nsplit, pc;
 };
+// NQ_WGRAD3_PC=0 keeps every layer on the 4-wave kernel (A/B runs of the two structures in one build)
+inline bool wgrad3_pc_enabled() {   // read per call: tools/bench_kernels.py flips it between launches of one process
+  const char* e = std::getenv("NQ_WGRAD3_PC");
+  return !(e && e[0] == '0');
+}
 inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
   Wg3Plan p;
   p.mi = pick_mi3(Cout);
@@ -154,6 +159,15 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
   if (ns > nseg) ns = nseg;
   if (ns < 1) ns = 1;
   p.nsplit = ns;
+  p.pc = 0;
+  // producer/consumer kernel (8 waves, ONE workgroup per CU): wide tiles with a long K loop per workgroup
+  if (wgrad3_pc_enabled() && p.ni >= 5 && p.mi >= 3 && tiles <= 256) {
+    int ns_pc = 256 / tiles;
+    if (ns_pc >= 1 && nseg / ns_pc >= 16) {
+      p.pc = 1;
+      p.nsplit = ns_pc;
+    }
+  }
   return p;
 }
 
@@ -290,8 +304,8 @@ int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float*
   float* slab = ws;
   float* slab_db = ws + (int64_t)p.nsplit * p.co_pad * p.n_pad;
   hipStream_t st = nq_s(stream);
-  int rc = (k == 3) ? nq_conv_wgrad3_k3(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, st)
-                    : nq_conv_wgrad3_k5(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, st);
+  int rc = (k == 3) ? nq_conv_wgrad3_k3(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, p.pc, st)
+                    : nq_conv_wgrad3_k5(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, p.pc, st);
   if (rc != NQ_OK) return rc;
   const int N = Cin * k * k;
   int64_t total = (int64_t)Cout * N + Cout;

@@ -338,6 +338,319 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 constexpr int ni3_for(int mi) { return mi <= 3 ? 6 : (mi <= 4 ? 6 : 6); }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Producer / consumer variant (8 waves, one workgroup per CU).  The loop above is bound by instruction ISSUE, not by the
+// matrix pipe: per 32-pixel segment a wave spends ~250 instructions on staging (global loads, the bf16 hi/lo split,
+// LDS stores) next to the ~200 that feed its 90 MFMAs.  Here the two jobs sit in different waves of the same SIMD:
+//   waves 0..3 (consumers): A fragments, just-in-time B fragments, MFMAs -- nothing else, the whole accumulator tile;
+//   waves 4..7 (producers): global loads two segments ahead (two register sets), split, LDS stores, bias-gradient sums.
+// Wave i and wave i+4 share a SIMD (waves are dealt to SIMDs cyclically), so the producer's VALU work issues in the
+// slots the consumer's MFMAs leave free (an MFMA holds the SIMD's vector issue for 8 of its 16 cycles) instead of
+// standing in front of them in one in-order stream.  Same LDS images, same arithmetic, same slab layout as above: results
+// are bit-identical for an equal split plan.  One barrier per segment, executed by all eight waves.
+template <int MI, int NI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad3p_kernel(Wgrad3Args a) {
+  constexpr int MT = 16 * MI, NT = 64 * NI;
+  constexpr int CIT = (NT + KK - 2) / KK + 1;
+  constexpr int DZ_U4 = 2 * 4 * MT;
+  constexpr int X_WORDS = CIT * PSX;
+  constexpr int BUF_BYTES = DZ_U4 * 16 + ((X_WORDS * 4 + 15) / 16) * 16;
+  constexpr int DITEMS = 4 * MT;
+  constexpr int DPT = (DITEMS + 255) / 256;
+  constexpr int Q = (RW + 3) / 4;
+  constexpr int XF = CIT * KS * Q;
+  constexpr int XPT4 = (XF + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int split = blockIdx.x;
+  const int n0 = blockIdx.y * NT;
+  const int co0 = blockIdx.z * MT;
+  const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, N = a.N;
+  const int ci0 = n0 / KK;
+  const int64_t HW = (int64_t)H * W;
+  const int seg_lo = (int)(((int64_t)a.nseg * split) / a.nsplit);
+  const int seg_hi = (int)(((int64_t)a.nseg * (split + 1)) / a.nsplit);
+
+  if (wave >= 4) {
+    // ============================================ producers ============================================
+    const int ptid = tid - 256;
+    // All global loads are bounds-checked BUFFER loads at 32-bit byte offsets with NO branch around them: an invalid
+    // item / an x row outside the image gets an out-of-range offset and reads as zero, only the partial quads at the
+    // left / right image edge (and the ragged tail of a row) are masked afterwards, under a wave-uniform branch.  A
+    // straight-line load sequence is what lets the compiler wait with a counted vmcnt(N) (see the loop below).
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.dy), 0, (int)(unsigned)((int64_t)a.B * Cout * HW * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.x), 0, (int)(unsigned)((int64_t)a.B * Cin * HW * 4), 0x00020000);
+    unsigned doff[DPT];
+    int dq8[DPT];
+    bool dok[DPT];
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) {
+      const int e = ptid + i * 256;
+      const int co = e >> 2;
+      dq8[i] = (e & 3) * 8;
+      dok[i] = (e < DITEMS) && (co0 + co < Cout);
+      doff[i] = (unsigned)(((int64_t)(co0 + co) * HW + dq8[i]) * 4);
+    }
+    int xoff[XPT4], xlds[XPT4], xrc[XPT4];
+#pragma unroll
+    for (int i = 0; i < XPT4; ++i) {
+      const int e = ptid + i * 256;
+      const int row = e / Q, q = e - row * Q;
+      const int ci_l = row / KS, r = row - ci_l * KS;
+      const bool ok = (e < XF) && (ci0 + ci_l < Cin);
+      xoff[i] = ((ci0 + ci_l) * (int)HW + (r - PAD) * W + 4 * q - PAD) * 4;   // bytes, relative to (b, channel 0, y, x0)
+      xlds[i] = ok ? ci_l * PSX + r * PWS + 4 * q : -1;
+      xrc[i] = r * 4096 + 4 * q;
+    }
+    float db_part[DPT];
+#pragma unroll
+    for (int i = 0; i < DPT; ++i) db_part[i] = 0.f;
+    const bool do_db = (blockIdx.y == 0) && a.slab_db != nullptr;
+
+    auto load_seg = [&](int seg, f32x4 (&dv)[DPT][2], f32x4 (&xv)[XPT4]) {
+      const int xs = seg % a.segs_x;
+      const int by = seg / a.segs_x;
+      const int y = by % H, b = by / H;
+      const int x0 = xs * SEG;
+      const unsigned dy_base = (unsigned)((((int64_t)b * Cout) * HW + (int64_t)y * W + x0) * 4);
+      const int x_base = (int)((((int64_t)b * Cin) * HW + (int64_t)y * W + x0) * 4);
+#pragma unroll
+      for (int i = 0; i < DPT; ++i) {
+        const unsigned off = dok[i] ? dy_base + doff[i] : OOB;
+        dv[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off, 0, 0));
+        dv[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, off + 16, 0, 0));
+      }
+#pragma unroll
+      for (int i = 0; i < XPT4; ++i) {
+        const int gy = y + (xrc[i] >> 12) - PAD;
+        const bool ok = (xlds[i] >= 0) && gy >= 0 && gy < H;
+        // a quad that starts before the very first element of the tensor (frame 0, channel 0, row 0, left halo) is loaded
+        // from offset 0 and shifted into place in store_seg: a negative offset would make the whole load read as zero
+        const unsigned off = ok ? (unsigned)max(x_base + xoff[i], 0) : OOB;
+        xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off, 0, 0));
+      }
+    };
+    // the edge masks are applied HERE, when the values are consumed (masking right after the loads would wait for them)
+    auto store_seg = [&](unsigned char* buf, int seg, f32x4 (&dv)[DPT][2], f32x4 (&xv)[XPT4]) {
+      const int x0 = (seg % a.segs_x) * SEG;
+      if (x0 + SEG > W) {   // ragged last segment of a row: pixels beyond the row end belong to the next row
+#pragma unroll
+        for (int i = 0; i < DPT; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (x0 + dq8[i] + j >= W) dv[i][0][j] = 0.f;
+            if (x0 + dq8[i] + 4 + j >= W) dv[i][1][j] = 0.f;
+          }
+      }
+      if (x0 < PAD || x0 + SEG + PAD > W) {   // halo columns outside the image (left / right edge segments)
+        const int by = seg / a.segs_x;
+        if (ci0 == 0 && by <= PAD && x0 == 0) {   // first rows of frame 0: the quad loaded from offset 0 (see load_seg)
+          const int x_base = by * W * 4;
+#pragma unroll
+          for (int i = 0; i < XPT4; ++i) {
+            if (xlds[i] >= 0 && x_base + xoff[i] < 0 && by + (xrc[i] >> 12) - PAD >= 0) {
+              const f32x4 v = xv[i];
+              if constexpr (PAD == 2) xv[i] = f32x4{0.f, 0.f, v[0], v[1]};
+              else if constexpr (PAD == 1) xv[i] = f32x4{0.f, v[0], v[1], v[2]};
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < XPT4; ++i) {
+          const int gx0 = x0 + (xrc[i] & 4095) - PAD;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (gx0 + j < 0 || gx0 + j >= W) xv[i][j] = 0.f;
+        }
+      }
+      u32x4* dz = reinterpret_cast<u32x4*>(buf);
+      unsigned* xw = reinterpret_cast<unsigned*>(buf + DZ_U4 * 16);
+#pragma unroll
+      for (int i = 0; i < DPT; ++i) {
+        const int e = ptid + i * 256;
+        if (e < DITEMS) {
+          const int co = e >> 2, q = e & 3;
+          u32x4 hi, lo;
+          float s = 0.f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float f0 = (j < 2) ? dv[i][0][2 * j] : dv[i][1][2 * j - 4];
+            const float f1 = (j < 2) ? dv[i][0][2 * j + 1] : dv[i][1][2 * j - 3];
+            s += f0 + f1;
+            const unsigned h2 = pk_bf16(f0, f1);
+            hi[j] = h2;
+            lo[j] = pk_bf16(f0 - lo_as_f32(h2), f1 - hi_as_f32(h2));
+          }
+          db_part[i] += s;
+          dz[oct_of(q) * MT + co] = hi;
+          dz[4 * MT + oct_of(q) * MT + co] = lo;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < XPT4; ++i) {
+        if (xlds[i] >= 0) {
+          const int cc = xrc[i] & 4095;
+          unsigned* d = xw + xlds[i];
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            const float f0 = xv[i][2 * jp], f1 = xv[i][2 * jp + 1];
+            const unsigned h2 = pk_bf16(f0, f1);
+            const unsigned l2 = pk_bf16(f0 - lo_as_f32(h2), f1 - hi_as_f32(h2));
+            const unsigned w0 = __builtin_amdgcn_perm(h2, l2, 0x05040100u);
+            const unsigned w1 = __builtin_amdgcn_perm(h2, l2, 0x07060302u);
+            if constexpr (4 * Q == RW) {
+              d[2 * jp] = w0;
+              d[2 * jp + 1] = w1;
+            } else {
+              if (cc + 2 * jp < RW) d[2 * jp] = w0;
+              if (cc + 2 * jp + 1 < RW) d[2 * jp + 1] = w1;
+            }
+          }
+        }
+      }
+    };
+
+    f32x4 dvA[DPT][2], xvA[XPT4], dvB[DPT][2], xvB[XPT4];
+    unsigned char* const buf0 = smem;
+    unsigned char* const buf1 = smem + BUF_BYTES;
+    // Loads are issued UNCONDITIONALLY (past the end of the split the last segment is simply loaded again and never
+    // stored): with a fixed number of younger loads in flight the compiler waits with a counted vmcnt(N) for the set it
+    // is about to convert, i.e. the other set's loads stay in flight across the barrier -- a conditional issue forces
+    // vmcnt(0) and exposes a full memory latency per segment.
+    const int seg_last = seg_hi - 1;
+    if (seg_lo < seg_hi) {
+      load_seg(seg_lo, dvA, xvA);
+      load_seg(min(seg_lo + 1, seg_last), dvB, xvB);
+      store_seg(buf0, seg_lo, dvA, xvA);
+      load_seg(min(seg_lo + 2, seg_last), dvA, xvA);
+    }
+    __syncthreads();  // P: segment seg_lo is staged
+    // Segments are walked in PAIRS with two barriers per pair on both sides (an odd tail just passes the second barrier):
+    // no early exit inside the body, so the in-flight load count the compiler reasons about is the same on every path.
+    for (int seg = seg_lo; seg < seg_hi; seg += 2) {
+      // consumers work on buf0 (segment seg); segment seg+1 (set B) goes to buf1, then set B is re-armed with seg+3
+      if (seg + 1 < seg_hi) store_seg(buf1, seg + 1, dvB, xvB);
+      load_seg(min(seg + 3, seg_last), dvB, xvB);
+      __syncthreads();
+      // consumers work on buf1 (segment seg+1); segment seg+2 (set A) goes to buf0, set A re-armed with seg+4
+      if (seg + 2 < seg_hi) store_seg(buf0, seg + 2, dvA, xvA);
+      load_seg(min(seg + 4, seg_last), dvA, xvA);
+      __syncthreads();
+    }
+    // bias gradient: per-thread fp32 sums of the staged dY values, combined in fixed order (all 8 waves pass the two
+    // barriers; the consumers are done with the LDS buffers after the loop's last barrier)
+    float* red = reinterpret_cast<float*>(smem);
+    if (do_db) {
+#pragma unroll
+      for (int i = 0; i < DPT; ++i) {
+        const int e = ptid + i * 256;
+        if (e < DITEMS) red[e] = db_part[i];   // red[co*4 + kq]
+      }
+    }
+    __syncthreads();
+    if (do_db && ptid < MT)
+      a.slab_db[(int64_t)split * a.co_pad + co0 + ptid] = (red[4 * ptid] + red[4 * ptid + 1]) + (red[4 * ptid + 2] + red[4 * ptid + 3]);
+    return;
+  }
+
+  // ============================================== consumers ==============================================
+  const int l16 = lane & 15, kq = lane >> 4;
+  int lc[NI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) {
+    int n = n0 + (wave * NI + ni) * 16 + l16;
+    if (n > N - 1) n = N - 1;
+    const int ci = n / KK, rem = n - ci * KK;
+    const int kh = rem / KS, kw = rem - kh * KS;
+    lc[ni] = (ci - ci0) * PSX + kh * PWS + kw + 8 * oct_of(kq);
+  }
+  const int a_lane = kq * MT + l16;
+  f32x4 acc[MI][NI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  __builtin_amdgcn_s_setprio(1);   // the MFMA stream wins issue arbitration against its producer partner
+  __syncthreads();  // P
+  auto compute = [&](int cur) {
+    const u32x4* __restrict__ dz = reinterpret_cast<const u32x4*>(smem + cur * BUF_BYTES) + a_lane;
+    const unsigned* __restrict__ xw = reinterpret_cast<const unsigned*>(smem + cur * BUF_BYTES + DZ_U4 * 16);
+    bf16x8 ah[MI], al[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      ah[mi] = __builtin_bit_cast(bf16x8, dz[mi * 16]);
+      al[mi] = __builtin_bit_cast(bf16x8, dz[4 * MT + mi * 16]);
+    }
+    auto build_B = [&](int ni, bf16x8& h, bf16x8& l) {
+      unsigned w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) w[j] = xw[lc[ni] + j];
+      u32x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hi[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x07060302u);
+        lo[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x05040100u);
+      }
+      h = __builtin_bit_cast(bf16x8, hi);
+      l = __builtin_bit_cast(bf16x8, lo);
+    };
+    bf16x8 bh0, bl0;
+    build_B(0, bh0, bl0);
+    wg3_steps<0, NI>([&](auto ni_c) {
+      constexpr int ni = decltype(ni_c)::value;
+      const bf16x8 bh = bh0, bl = bl0;
+      if constexpr (ni + 1 < NI) build_B(ni + 1, bh0, bl0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+    });
+  };
+  for (int seg = seg_lo; seg < seg_hi; seg += 2) {   // pairs, two barriers per pair (mirrors the producers)
+    compute(0);
+    __syncthreads();
+    if (seg + 1 < seg_hi) compute(1);
+    __syncthreads();
+  }
+  __builtin_amdgcn_s_setprio(0);
+  __syncthreads();   // pairs with the producers' bias-gradient barrier
+
+  float* __restrict__ slab = a.slab + (int64_t)split * a.co_pad * a.n_pad;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+      const int n = n0 + (wave * NI + ni) * 16 + l16;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int co = co0 + mi * 16 + 4 * kq + reg;
+        slab[(int64_t)co * a.n_pad + n] = acc[mi][ni][reg];
+      }
+    }
+}
+
+template <int MI, int NI>
+int launch_wgrad3p(const Wgrad3Args& a, hipStream_t st) {
+  constexpr int MT = 16 * MI, NT = 64 * NI;
+  constexpr int CIT = (NT + KK - 2) / KK + 1;
+  constexpr int BUF_BYTES = 2 * 4 * MT * 16 + ((CIT * PSX * 4 + 15) / 16) * 16;
+  size_t lds = (size_t)2 * BUF_BYTES;
+  dim3 grid((unsigned)a.nsplit, (unsigned)(a.n_pad / NT), (unsigned)(a.co_pad / MT));
+  if (int rc = nq_lds_optin<&conv_wgrad3p_kernel<MI, NI>>(lds)) return rc;
+  hipLaunchKernelGGL((conv_wgrad3p_kernel<MI, NI>), grid, dim3(512), lds, st, a);
+  return nq_launch_status();
+}
+
+
 template <int MI, int NI>
 int launch_wgrad3(const Wgrad3Args& a, hipStream_t st) {
   constexpr int MT = 16 * MI, NT = 64 * NI;
@@ -359,7 +672,7 @@ int launch_wgrad3(const Wgrad3Args& a, hipStream_t st) {
 // or 1 for C_in*k*k <= 64)
 extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, float* slab, float* slab_db, int B, int Cin,
                                                 int H, int W, int Cout, int co_pad, int n_pad, int nsplit, int mi_sel,
-                                                int ni_sel, hipStream_t st) {
+                                                int ni_sel, int pc, hipStream_t st) {
   Wgrad3Args a;
   a.x = x; a.dy = dy; a.slab = slab; a.slab_db = slab_db;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.N = Cin * KK;
@@ -367,6 +680,32 @@ extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, 
   a.segs_x = (W + SEG - 1) / SEG;
   a.nseg = a.segs_x * H * B;
   a.nsplit = nsplit;
+  if (pc) {   // producer / consumer variant (wide n-tiles only; the plan sized nsplit for one 8-wave workgroup per CU)
+    if (ni_sel == 5) {
+      switch (mi_sel) {
+        case 3: return launch_wgrad3p<3, 5>(a, st);
+        case 4: return launch_wgrad3p<4, 5>(a, st);
+        case 5: return launch_wgrad3p<5, 5>(a, st);
+        default: return NQ_ERR_UNSUPPORTED;
+      }
+    }
+    if (ni_sel == 6) {
+      switch (mi_sel) {
+        case 3: return launch_wgrad3p<3, 6>(a, st);
+        case 4: return launch_wgrad3p<4, 6>(a, st);
+        case 5: return launch_wgrad3p<5, 6>(a, st);
+        default: return NQ_ERR_UNSUPPORTED;
+      }
+    }
+    if (ni_sel == 7) {
+      switch (mi_sel) {
+        case 3: return launch_wgrad3p<3, 7>(a, st);
+        case 4: return launch_wgrad3p<4, 7>(a, st);
+        default: return NQ_ERR_UNSUPPORTED;
+      }
+    }
+    return NQ_ERR_UNSUPPORTED;
+  }
   if (ni_sel == 1) {
     switch (mi_sel) {
       case 1: return launch_wgrad3<1, 1>(a, st);

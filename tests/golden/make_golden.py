@@ -22,6 +22,8 @@ Fixtures (what each one pins; reference file:line):
   traj_hnerv.npz     tiny HNeRV: checkpoint, embeddings, batch order, per-iteration losses of the
                      real model_reconstruction, final alpha/delta/x_quant, PSNRs    calib_model.py:92-240
   traj_nerv_had.npz  tiny NeRV + Hadamard: same (FWHT via stub -> "parity unpinned" at the transform)
+  config1_hnerv3m.npz  BASELINE configs[0] at FULL size with the real reference: HNeRV-3M (trained checkpoint
+                     hnerv3m_bunny8_f16.npz), 8 frames of 640x1280, 48 iterations: loss log + PSNRs     calib_model.py:92-240
   omega.npz          tiny HNeRV (checkpoint of traj_hnerv.npz): get_perturbation() and the reference's own
                      sensitivity_criterion ('omega' = v'Hv by double backward, 'fisher_diag') for the two toy
                      candidates of bit_assign.py:27-30                          bit_assign.py:57-217
@@ -574,6 +576,82 @@ def gen_omega():
     save("omega.npz", **out)
 
 
+HNERV_3M = dict(crop_h=640, crop_w=1280, diff_enc=False, stage_block=1, enc_strides=[5, 4, 4, 2, 2],
+                enc_channel=[64, 64, 64, 64, 16], channel_reduce=1.2, channel_lbound=12, dec_in_channel=92,
+                dec_kernels=[1, 3, 5, 5, 5], dec_strides=[5, 4, 4, 2, 2], dec_norm="none", dec_acts="gelu",
+                out_bias="tanh")
+
+
+def gen_config1():
+    """BASELINE configs[0] with the REAL reference at full size: HNeRV Bunny_1280x640_3M, the trained
+    checkpoint of hnerv3m_bunny8_f16.npz (make_ckpt_fixture.py), 8 Bunny-derived 640x1280 frames (frames_320x640.npz with
+    every pixel repeated 2x2), --precision 6 5 4 5 5 6 6, batch 2, iters_w = 50 -> 0 phase-1 epochs + 12 phase-2 epochs =
+    48 iterations of the reference's own model_reconstruction.  Stored: the recorded batch order, the 48-entry loss log,
+    per-frame PSNRs (FP / quant w/o opt / quant w/ opt), initial scales.  ~4 min of CPU."""
+    ck = np.load(os.path.join(HERE, "hnerv3m_bunny8_f16.npz"))
+    small = np.load(os.path.join(HERE, "frames_320x640.npz"))["frames"]
+    frames = torch.from_numpy(np.repeat(np.repeat(small, 2, axis=2), 2, axis=3).copy()).float() / 255.0
+    n, B, iters = frames.shape[0], 2, 50
+    torch.manual_seed(1)
+    model = HNeRV(HNERV_3M)
+    sd = {k[3:].replace("/", "."): torch.from_numpy(ck[k].astype(np.float32)) for k in ck.files if k.startswith("sd:")}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.startswith("encoder") for m in missing), (missing, unexpected)
+    model.eval()
+    emb = torch.from_numpy(ck["emb"])
+    out = {}
+    with torch.no_grad():
+        y_fp = torch.cat([model.decode(emb[i:i + 1])[0] for i in range(n)], 0)
+    out["psnr_fp"] = npy(psnr_frames(y_fp, frames))
+    print("  FP psnr", out["psnr_fp"].mean(), flush=True)
+    qnn = QuantModel(model=model, hadamard=False, weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
+    out["avgbits"] = np.array(qnn.set_bitwidth(BITS), dtype=np.float64)
+    qnn.eval()
+    qnn.set_quant_state(True)
+    with torch.no_grad():
+        qnn(emb[:B])
+        y_q0 = torch.cat([qnn(emb[i:i + 1])[0] for i in range(n)], 0)
+    out["psnr_q_noopt"] = npy(psnr_frames(y_q0, frames))
+    print("  quant w/o opt psnr", out["psnr_q_noopt"].mean(), flush=True)
+    qms = [m for m in qnn.model.modules() if isinstance(m, QuantModule)]
+    for li, m in enumerate(qms):
+        out[f"init_wdelta{li}"] = npy(m.weight_quantizer.delta)
+        out[f"init_bdelta{li}"] = npy(m.bias_quantizer.delta)
+    g = torch.Generator().manual_seed(903)
+    n_ep = iters // (n // B)
+    order = torch.stack([torch.randperm(n, generator=g)[: (n // B) * B].view(n // B, B) for _ in range(n_ep)]).numpy()
+    out["order"] = order
+    loader = ReplayLoader(frames, order, n)
+    log = []
+    orig_call = ref_calib.LossFunction.__call__
+
+    def recording_call(self, pred, tgt, grad=None):
+        total = orig_call(self, pred, tgt, grad)
+        b = self.temp_decay(self.count)
+        if self.count < self.loss_start or self.round == "none":
+            b = 0
+        log.append((float(total), float(self.round_loss), float(b), self.count))
+        return total
+
+    ref_calib.LossFunction.__call__ = recording_call
+    t0 = time.time()
+    try:
+        ref_calib.model_reconstruction(qnn, cali_data=emb, gt=loader, arch="hnerv", batch_size=B, iters=iters, weight=0.01,
+                                       opt_mode="mse", hadamard=False, b_range=(20, 2), warmup=0.2, p=2.0, lr=0.003)
+    finally:
+        ref_calib.LossFunction.__call__ = orig_call
+    print(f"  model_reconstruction: {len(log)} iterations in {time.time() - t0:.1f}s", flush=True)
+    out["loss_log"] = np.array(log, dtype=np.float64)
+    out["iters"] = np.array(iters)
+    out["seconds_cpu8"] = np.array(time.time() - t0)
+    qnn.set_quant_state(True)
+    with torch.no_grad():
+        y_q1 = torch.cat([qnn(emb[i:i + 1])[0] for i in range(n)], 0)
+    out["psnr_q_opt"] = npy(psnr_frames(y_q1, frames))
+    print("  quant w/ opt psnr", out["psnr_q_opt"].mean(), flush=True)
+    save("config1_hnerv3m.npz", **out)
+
+
 GENS = {
     "uaq": gen_uaq,
     "adaround": gen_adaround,
@@ -586,6 +664,7 @@ GENS = {
     "traj_hnerv": lambda: gen_traj("traj_hnerv.npz", "hnerv", HNeRV, TINY_HNERV, False, 400, 150, 2e-3, 903),
     "traj_nerv_had": lambda: gen_traj("traj_nerv_had.npz", "nerv", NeRV, TINY_NERV, True, 200, 150, 2e-3, 904),
     "omega": gen_omega,
+    "config1": gen_config1,
 }
 
 if __name__ == "__main__":

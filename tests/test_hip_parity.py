@@ -292,7 +292,10 @@ def test_conv_bf16x3(ops, case):
 
 
 @pytest.mark.parametrize("case", [(2, 44, 24, 96, 148, 5), (1, 53, 17, 70, 176, 5), (2, 64, 12, 40, 848, 5), (2, 64, 40, 80, 848, 5),
-                                  (2, 20, 33, 100, 96, 3), (3, 9, 16, 64, 36, 3), (1, 37, 40, 64, 12, 3)])
+                                  (2, 20, 33, 100, 96, 3), (3, 9, 16, 64, 36, 3), (1, 37, 40, 64, 12, 3),
+                                  # enough 32-pixel segments per workgroup for the producer/consumer kernel (8 waves, one
+                                  # workgroup per CU): dec5 / dec4 channel geometry, ragged last segment in the second
+                                  (2, 44, 48, 224, 148, 5), (1, 53, 66, 216, 176, 5), (2, 36, 128, 256, 96, 3)])
 def test_wgrad_bf16x3(ops, case):
     """bf16x3 weight/bias gradient vs float64 (error at the fp32 level relative to the gradient scale); deterministic."""
     B, Cin, H, W, Cout, k = case
