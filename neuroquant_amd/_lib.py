@@ -5,7 +5,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p, POINTER, Structure
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnqhip.so")
+# NQ_LIB points the loader at another build of the SAME library (kernel A/B runs, tools/bench_kernels.py); default in-tree
+LIB_PATH = os.environ.get("NQ_LIB") or os.path.join(_HERE, "libnqhip.so")
 
 NQ_OK = 0
 EPI_PLAIN, EPI_PS_GELU, EPI_TANH, EPI_PS, EPI_DGRAD_GELU = 0, 1, 2, 3, 4

@@ -13,6 +13,7 @@
 // Operands are split (two v_cvt_pk_bf16_f32 + one subtract per element) once, while staging.
 //
 // Roofline: MFMA bf16, 3 MFMA flops per algorithmic flop (833 TFLOP/s fp32-equivalent); algorithmic flops as fp32.
+#include <cstdlib>
 #include <type_traits>
 
 #include "nq_common.h"
@@ -34,6 +35,7 @@ struct Wgrad3Args {
   float* slab;     // [nsplit][co_pad][n_pad]
   float* slab_db;  // [nsplit][co_pad]
   int B, Cin, H, W, Cout, N, co_pad, n_pad, segs_x, nseg, nsplit;
+  int dbg;  // timing experiments only (NQ_WG3_DBG): 1 = load one x row of five, 2 = producers skip the conversion, 3 = consumers skip the MFMAs
 };
 
 constexpr int KS = NQ_KS;
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int i = 0; i < XPT4; ++i) {
         const int gy = y + (xrc[i] >> 12) - PAD;
-        const bool ok = (xlds[i] >= 0) && gy >= 0 && gy < H;
+        const bool ok = (xlds[i] >= 0) && gy >= 0 && gy < H && (a.dbg != 1 || (xrc[i] >> 12) == PAD);
         // a quad that starts before the very first element of the tensor (frame 0, channel 0, row 0, left halo) is loaded
         // from offset 0 and shifted into place in store_seg: a negative offset would make the whole load read as zero
         const unsigned off = ok ? (unsigned)max(x_base + xoff[i], 0) : OOB;
@@ -535,11 +537,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // no early exit inside the body, so the in-flight load count the compiler reasons about is the same on every path.
     for (int seg = seg_lo; seg < seg_hi; seg += 2) {
       // consumers work on buf0 (segment seg); segment seg+1 (set B) goes to buf1, then set B is re-armed with seg+3
-      if (seg + 1 < seg_hi) store_seg(buf1, seg + 1, dvB, xvB);
+      if (seg + 1 < seg_hi && a.dbg != 2) store_seg(buf1, seg + 1, dvB, xvB);
       load_seg(min(seg + 3, seg_last), dvB, xvB);
       __syncthreads();
       // consumers work on buf1 (segment seg+1); segment seg+2 (set A) goes to buf0, set A re-armed with seg+4
-      if (seg + 2 < seg_hi) store_seg(buf0, seg + 2, dvA, xvA);
+      if (seg + 2 < seg_hi && a.dbg != 2) store_seg(buf0, seg + 2, dvA, xvA);
       load_seg(min(seg + 4, seg_last), dvA, xvA);
       __syncthreads();
     }
@@ -616,9 +618,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     });
   };
   for (int seg = seg_lo; seg < seg_hi; seg += 2) {   // pairs, two barriers per pair (mirrors the producers)
-    compute(0);
+    if (a.dbg != 3) compute(0);
     __syncthreads();
-    if (seg + 1 < seg_hi) compute(1);
+    if (seg + 1 < seg_hi && a.dbg != 3) compute(1);
     __syncthreads();
   }
   __builtin_amdgcn_s_setprio(0);
@@ -680,6 +682,10 @@ extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, 
   a.segs_x = (W + SEG - 1) / SEG;
   a.nseg = a.segs_x * H * B;
   a.nsplit = nsplit;
+  {
+    const char* e = std::getenv("NQ_WG3_DBG");
+    a.dbg = e ? atoi(e) : 0;
+  }
   if (pc) {   // producer / consumer variant (wide n-tiles only; the plan sized nsplit for one 8-wave workgroup per CU)
     if (ni_sel == 5) {
       switch (mi_sel) {

@@ -317,3 +317,25 @@ def test_trajectory_sensitivity_fixture(golden):
     rel = np.abs(log[:, 0] - z["loss_log"][:60, 0]) / np.abs(z["loss_log"][:60, 0])
     assert rel[:3].max() <= 2e-4
     assert 1e-4 < rel.max() <= 3 * sens["hnerv"]["spread"]["loss_rel_all"], rel.max()
+
+
+def test_config1_reference_fixture_oracle(golden):
+    """The oracle against the full-size reference fixture (config1_hnerv3m.npz: the real reference's model_reconstruction on
+    HNeRV-3M at 640x1280): initial scales bit-exact, PSNR of the quantised model, and the first 3 of its 48 logged
+    iterations (the CPU suite stays short; the GPU suite checks all 48 against the same fixture)."""
+    z, ck = golden("config1_hnerv3m.npz"), golden("hnerv3m_bunny8_f16.npz")
+    small = golden("frames_320x640.npz")["frames"]
+    frames = torch.from_numpy(np.repeat(np.repeat(small, 2, axis=2), 2, axis=3).copy()).float() / 255.0
+    sd = {k[3:].replace("/", "."): torch.from_numpy(v.astype(np.float32)) for k, v in ck.items() if k.startswith("sd:")}
+    dec = O.Decoder.from_state_dict(sd, "hnerv", [5, 4, 4, 2, 2])
+    qs = O.QuantStack(dec, BITS, hadamard=False)
+    assert qs.avg_bits() == float(z["avgbits"])
+    for li, L in enumerate(dec.layers):
+        eq(L.wd, z[f"init_wdelta{li}"]); eq(L.bd.view(-1), z[f"init_bdelta{li}"].reshape(-1))
+    emb = T(ck["emb"])
+    with torch.no_grad():
+        eq(O.psnr_per_frame(qs.forward(emb[:2]), frames[:2]), z["psnr_q_noopt"][:2], atol=1e-3)
+    log = np.array(O.calibrate(qs, emb, frames, z["order"], int(z["iters"]), max_steps=3))
+    eq(log[:, 2:], z["loss_log"][:3, 2:])
+    eq(log[:, 0], z["loss_log"][:3, 0], rtol=2e-5)
+    eq(log[:, 1], z["loss_log"][:3, 1], rtol=2e-5)

@@ -61,7 +61,15 @@ def main():
             def wg(pc, x=x, dy=dy, cout=cout, k=k):
                 os.environ["NQ_WGRAD3_PC"] = pc
                 return ops.conv_wgrad3_raw(x, dy, cout, k, True)
-            cases.append((f"{name} wgrad3 {cin}x{cout}", flops, {"4wave": lambda wg=wg: wg("0"), "prod/cons": lambda wg=wg: wg("1")}))
+            def wgd(d, wg=wg):
+                os.environ["NQ_WG3_DBG"] = d
+                r = wg("1")
+                os.environ["NQ_WG3_DBG"] = "0"
+                return r
+            var = {"4wave": lambda wg=wg: wg("0"), "prod/cons": lambda wg=wg: wg("1")}
+            if os.environ.get("NQ_BENCH_DBG"):
+                var.update({"pc x1row": lambda wgd=wgd: wgd("1"), "pc noconv": lambda wgd=wgd: wgd("2"), "pc nomfma": lambda wgd=wgd: wgd("3")})
+            cases.append((f"{name} wgrad3 {cin}x{cout}", flops, var))
     cases = [c for c in cases if args.only in c[0]]
     for name, flops, variants in cases:
         for fn in variants.values():

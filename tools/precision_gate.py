@@ -253,10 +253,10 @@ def run(args, log=print):
         ep1 = int(0.05 * it_o / (n // B)) * (n // B)
         res["oracle"] = {"iters_w": it_o, "iterations": int(len(clog)), "phase1_iterations": ep1, "cpu": c, "gpu_fp32": g,
                          "gpu_bf16x3": g3,
-                         "loss_rel_diff_fp32": {"first3": float(rel[:3].max()), "phase1_max": float(rel[:ep1].max()),
-                                                "max": float(rel.max())},
-                         "loss_rel_diff_bf16x3": {"first3": float(rel3[:3].max()), "phase1_max": float(rel3[:ep1].max()),
-                                                  "max": float(rel3.max())},
+                         "loss_rel_diff_fp32": {"first": float(rel[0]), "first3": float(rel[:3].max()),
+                                                "phase1_max": float(rel[:ep1].max()), "max": float(rel.max())},
+                         "loss_rel_diff_bf16x3": {"first": float(rel3[0]), "first3": float(rel3[:3].max()),
+                                                  "phase1_max": float(rel3[:ep1].max()), "max": float(rel3.max())},
                          "dpsnr_fp32_dB": abs(g["q_opt"] - c["q_opt"]), "dpsnr_bf16x3_dB": abs(g3["q_opt"] - c["q_opt"]),
                          "cpu_threads": args.cpu_threads}
         log(f"oracle {it_o} iters: CPU {c['q_opt']:.4f} dB ({c['seconds']:.0f}s), GPU fp32 {g['q_opt']:.4f}, bf16x3 {g3['q_opt']:.4f}; "
