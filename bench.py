@@ -17,7 +17,7 @@ Scaling modes:
                      iterations/s.
 
 Prints ONE JSON line (rank 0) with
-  `roofline`      dominant kernel of the timed (default-precision, bf16x3) run, HIP-event timed inside every 5th step;
+  `roofline`      dominant kernel of the timed (default-precision, bf16x3) run, HIP-event timed inside every 10th step;
   `fp32`          the same workload re-timed with exact-fp32 MFMA convolutions (NQ_CONV_PRECISION=fp32) and its roofline;
   `psnr`          BASELINE configs[0] (8 Bunny-derived 640x1280 frames, iters_w = 50) on a checkpoint trained here:
                   final PSNR of the CPU oracle, the GPU with exact fp32 and the GPU with bf16x3 (bar: within 0.02 dB);
@@ -51,7 +51,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_BF16X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
 FLAGS = dict(weight=0.01, b_range=(20, 2), lr=0.003)
-PROF_EVERY = 5   # HIP events around the conv launches of every 5th timed step (the records themselves cost time)
+PROF_EVERY = 10  # HIP events around the conv launches of every 10th timed step: those steps are launched eagerly (~1.2 ms of
+                 # host work each), all others are hipGraph replays
 
 
 def build_model(seed=903, workload="hnerv"):

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""profiles/hbm_traffic.json (what bench.py reports as roofline.traffic) from a PMC summary made by summarize.py.
+
+    python3 profiles/make_traffic.py profiles/r02_a_pmc_conv_kernels.json
+
+bytes = read + write per launch at per-GPU batch 2: FETCH_SIZE x 2 (gfx950 reports half the bytes of 16-byte-per-lane
+streaming reads, MI355X_MICROARCH.md §HBM; separate --pmc pass) + WRITE_SIZE (its own pass).  FETCH_SIZE counts the L2's
+fabric-side requests, Infinity-Cache hits included (same guide), so for kernels whose workgroups re-read a tile that is
+still resident in the 256 MiB cache it is an UPPER reading of the HBM bytes.  bench.py only reports an entry while the
+live kernel duration is within 20 % of `dur_us` recorded here (profiled runs are a few % slower than plain ones).
+"""
+import json
+import sys
+
+# bench key -> (kernel name in the PMC summary, grid size) for HNeRV Bunny_1280x640_3M, B = 2
+MAP = {
+    "conv_wgrad3_k5_44_148": ("conv_wgrad3p_kernel<5, 6>", None),
+    "conv_igemm3_k5_44_148": ("conv_igemm3_kernel<5>", 819200),
+    "conv_igemm3_k5_148_44": ("conv_igemm3_kernel<3>", 409600),
+    "conv_wgrad3_k5_53_176": ("conv_wgrad3p_kernel<4, 7>", None),
+    "conv_igemm3_k5_53_176": ("conv_igemm3_kernel<4>", 307200),
+    "conv_igemm3_k5_176_53": ("conv_igemm3_kernel<4>", 102400),
+}
+
+
+def main(src):
+    rows = json.load(open(src))
+    out = {}
+    for key, (name, grid) in MAP.items():
+        for r in rows:
+            if r["kernel"] == name and (grid is None or r["grid"] == grid):
+                rd, wr = r["hbm_read_MB"] * 1e6, (r["hbm_write_MB"] or 0) * 1e6
+                out[key] = dict(bytes=int(rd + wr), read_bytes=int(rd), write_bytes=int(wr), read_factor=2, batch=2,
+                                kernel=name, dur_us=r["dur_us"], mfma_busy=r.get("mfma_busy_frac"), source=src)
+                break
+    json.dump(out, open("profiles/hbm_traffic.json", "w"), indent=1)
+    for k, v in out.items():
+        print(k, v["bytes"], v["dur_us"])
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

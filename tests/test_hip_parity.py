@@ -766,9 +766,18 @@ def test_fp32_trainer_step_matches_torch(golden):
     out_c, _, _ = mc(img_c)
     F.mse_loss(out_c, img_c).backward(); oc.step()
     close(out_g, out_c, rtol=1e-4, atol=3e-5)
+    n_enc = 0
     for (n, pg), (_, pc) in zip(mg.named_parameters(), mc.named_parameters()):
-        if n.startswith("decoder") or n.startswith("head"):
-            close(pg.grad, pc.grad, rtol=5e-3, atol=2e-4 * float(pc.grad.abs().max()) + 1e-9)
+        # EVERY parameter: the fused decoder node also returns d(embedding) (data gradient through layer 0), so the
+        # ConvNeXt encoder below it trains too (reference regress.py:259-266 optimises model.parameters())
+        assert pg.grad is not None, f"{n} got no gradient"
+        close(pg.grad, pc.grad, rtol=5e-3, atol=2e-4 * float(pc.grad.abs().max()) + 1e-9)
+        n_enc += n.startswith("encoder")
+    assert n_enc > 10
+    # and after the Adam step the encoder has moved like the CPU model's
+    for (n, pg), (_, pc) in zip(mg.named_parameters(), mc.named_parameters()):
+        if n.startswith("encoder") and pg.dim() > 1:
+            close(pg, pc, rtol=1e-3, atol=2e-4)
 
 
 # ------------------------------------------------------------------------------------------ Omega bit allocation
