@@ -128,6 +128,10 @@ struct Wg3Plan {
   int mi, ni, co_pad, n_pad, nsplit, pc;
 };
 // NQ_WGRAD3_PC=0 keeps every layer on the 4-wave kernel (A/B runs of the two structures in one build)
+inline bool wgrad3_ss1() {   // NQ_WGRAD3_SS=1: 32-pixel segments only (A/B runs)
+  const char* e = std::getenv("NQ_WGRAD3_SS");
+  return e && e[0] == '1';
+}
 inline bool wgrad3_pc_enabled() {   // read per call: tools/bench_kernels.py flips it between launches of one process
   const char* e = std::getenv("NQ_WGRAD3_PC");
   return !(e && e[0] == '0');
@@ -162,9 +166,11 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
   p.pc = 0;
   // producer/consumer kernel (8 waves, ONE workgroup per CU): wide tiles with a long K loop per workgroup
   if (wgrad3_pc_enabled() && p.ni >= 5 && p.mi >= 3 && tiles <= 256) {
+    const int ss = (W % 64 == 0 && !wgrad3_ss1()) ? 2 : 1;   // 64-pixel segments where rows divide evenly
+    const int nseg_pc = ((W + 32 * ss - 1) / (32 * ss)) * H * B;
     int ns_pc = 256 / tiles;
-    if (ns_pc >= 1 && nseg / ns_pc >= 16) {
-      p.pc = 1;
+    if (ns_pc >= 1 && nseg_pc / ns_pc >= 8 * (3 - ss)) {
+      p.pc = ss;
       p.nsplit = ns_pc;
     }
   }

@@ -350,14 +350,25 @@ constexpr int ni3_for(int mi) { return mi <= 3 ? 6 : (mi <= 4 ? 6 : 6); }
 // slots the consumer's MFMAs leave free (an MFMA holds the SIMD's vector issue for 8 of its 16 cycles) instead of
 // standing in front of them in one in-order stream.  Same LDS images, same arithmetic, same slab layout as above: results
 // are bit-identical for an equal split plan.  One barrier per segment, executed by all eight waves.
-template <int MI, int NI>
+template <int MI, int NI, int SS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad3p_kernel(Wgrad3Args a) {
+  // SS = 32-pixel MFMA k-steps per staged segment (segment = 32*SS pixels of one image row, one barrier each): SS = 2
+  // halves the barriers and the consumers' start-up (first fragments after a barrier) per MFMA where rows are a
+  // multiple of 64 pixels
   constexpr int MT = 16 * MI, NT = 64 * NI;
+  constexpr int SEG = 32 * SS;
+  constexpr int RW = SEG + KS - 1;
+  constexpr int PWS = [] {  // x row stride (words): >= RW and == KS (mod 32)
+    int v = RW;
+    while (v % 32 != KS % 32) ++v;
+    return v;
+  }();
+  constexpr int PSX = KS * PWS;
   constexpr int CIT = (NT + KK - 2) / KK + 1;
-  constexpr int DZ_U4 = 2 * 4 * MT;
+  constexpr int DZ_U4 = SS * 2 * 4 * MT;       // 16-byte units: [k-step][plane][kq][MT]
   constexpr int X_WORDS = CIT * PSX;
   constexpr int BUF_BYTES = DZ_U4 * 16 + ((X_WORDS * 4 + 15) / 16) * 16;
-  constexpr int DITEMS = 4 * MT;
+  constexpr int DITEMS = SS * 4 * MT;          // (co, pixel octet) staging items
   constexpr int DPT = (DITEMS + 255) / 256;
   constexpr int Q = (RW + 3) / 4;
   constexpr int XF = CIT * KS * Q;
@@ -394,8 +405,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < DPT; ++i) {
       const int e = ptid + i * 256;
-      const int co = e >> 2;
-      dq8[i] = (e & 3) * 8;
+      const int co = e / (4 * SS);
+      dq8[i] = (e % (4 * SS)) * 8;
       dok[i] = (e < DITEMS) && (co0 + co < Cout);
       doff[i] = (unsigned)(((int64_t)(co0 + co) * HW + dq8[i]) * 4);
     }
@@ -477,7 +488,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int i = 0; i < DPT; ++i) {
         const int e = ptid + i * 256;
         if (e < DITEMS) {
-          const int co = e >> 2, q = e & 3;
+          const int co = e / (4 * SS), oct = e % (4 * SS), sub = oct >> 2, q = oct & 3;
           u32x4 hi, lo;
           float s = 0.f;
 #pragma unroll
@@ -490,8 +501,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             lo[j] = pk_bf16(f0 - lo_as_f32(h2), f1 - hi_as_f32(h2));
           }
           db_part[i] += s;
-          dz[oct_of(q) * MT + co] = hi;
-          dz[4 * MT + oct_of(q) * MT + co] = lo;
+          dz[sub * 8 * MT + oct_of(q) * MT + co] = hi;       // pixel octet q of k-step sub is held by lane group oct_of(q)
+          dz[sub * 8 * MT + 4 * MT + oct_of(q) * MT + co] = lo;
         }
       }
 #pragma unroll
@@ -537,11 +548,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // no early exit inside the body, so the in-flight load count the compiler reasons about is the same on every path.
     for (int seg = seg_lo; seg < seg_hi; seg += 2) {
       // consumers work on buf0 (segment seg); segment seg+1 (set B) goes to buf1, then set B is re-armed with seg+3
-      if (seg + 1 < seg_hi && a.dbg != 2) store_seg(buf1, seg + 1, dvB, xvB);
+      if (seg + 1 < seg_hi && a.dbg != 2 && a.dbg != 5) store_seg(buf1, seg + 1, dvB, xvB);
       load_seg(min(seg + 3, seg_last), dvB, xvB);
       __syncthreads();
       // consumers work on buf1 (segment seg+1); segment seg+2 (set A) goes to buf0, set A re-armed with seg+4
-      if (seg + 2 < seg_hi && a.dbg != 2) store_seg(buf0, seg + 2, dvA, xvA);
+      if (seg + 2 < seg_hi && a.dbg != 2 && a.dbg != 5) store_seg(buf0, seg + 2, dvA, xvA);
       load_seg(min(seg + 4, seg_last), dvA, xvA);
       __syncthreads();
     }
@@ -552,12 +563,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int i = 0; i < DPT; ++i) {
         const int e = ptid + i * 256;
-        if (e < DITEMS) red[e] = db_part[i];   // red[co*4 + kq]
+        if (e < DITEMS) red[e] = db_part[i];   // red[co*(4*SS) + octet]
       }
     }
     __syncthreads();
     if (do_db && ptid < MT)
-      a.slab_db[(int64_t)split * a.co_pad + co0 + ptid] = (red[4 * ptid] + red[4 * ptid + 1]) + (red[4 * ptid + 2] + red[4 * ptid + 3]);
+    {
+      float t = 0.f;
+#pragma unroll
+      for (int sub = 0; sub < SS; ++sub) {
+        const float* r4 = red + (4 * SS) * ptid + 4 * sub;
+        t += (r4[0] + r4[1]) + (r4[2] + r4[3]);
+      }
+      a.slab_db[(int64_t)split * a.co_pad + co0 + ptid] = t;
+    }
     return;
   }
 
@@ -582,40 +601,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __builtin_amdgcn_s_setprio(1);   // the MFMA stream wins issue arbitration against its producer partner
   __syncthreads();  // P
   auto compute = [&](int cur) {
-    const u32x4* __restrict__ dz = reinterpret_cast<const u32x4*>(smem + cur * BUF_BYTES) + a_lane;
-    const unsigned* __restrict__ xw = reinterpret_cast<const unsigned*>(smem + cur * BUF_BYTES + DZ_U4 * 16);
-    bf16x8 ah[MI], al[MI];
+    const u32x4* __restrict__ dz0 = reinterpret_cast<const u32x4*>(smem + cur * BUF_BYTES) + a_lane;
+    const unsigned* __restrict__ xw0 = reinterpret_cast<const unsigned*>(smem + cur * BUF_BYTES + DZ_U4 * 16);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      ah[mi] = __builtin_bit_cast(bf16x8, dz[mi * 16]);
-      al[mi] = __builtin_bit_cast(bf16x8, dz[4 * MT + mi * 16]);
-    }
-    auto build_B = [&](int ni, bf16x8& h, bf16x8& l) {
-      unsigned w[8];
+    for (int sub = 0; sub < SS; ++sub) {
+      const u32x4* __restrict__ dz = dz0 + sub * 8 * MT;
+      const unsigned* __restrict__ xw = xw0 + 32 * sub;
+      bf16x8 ah[MI], al[MI];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) w[j] = xw[lc[ni] + j];
-      u32x4 hi, lo;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        hi[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x07060302u);
-        lo[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x05040100u);
+      for (int mi = 0; mi < MI; ++mi) {
+        ah[mi] = __builtin_bit_cast(bf16x8, dz[mi * 16]);
+        al[mi] = __builtin_bit_cast(bf16x8, dz[4 * MT + mi * 16]);
       }
-      h = __builtin_bit_cast(bf16x8, hi);
-      l = __builtin_bit_cast(bf16x8, lo);
-    };
-    bf16x8 bh0, bl0;
-    build_B(0, bh0, bl0);
-    wg3_steps<0, NI>([&](auto ni_c) {
-      constexpr int ni = decltype(ni_c)::value;
-      const bf16x8 bh = bh0, bl = bl0;
-      if constexpr (ni + 1 < NI) build_B(ni + 1, bh0, bl0);
+      auto build_B = [&](int ni, bf16x8& h, bf16x8& l) {
+        unsigned w[8];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+        for (int j = 0; j < 8; ++j) w[j] = xw[lc[ni] + j];
+        u32x4 hi, lo;
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+          hi[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x07060302u);
+          lo[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x05040100u);
+        }
+        h = __builtin_bit_cast(bf16x8, hi);
+        l = __builtin_bit_cast(bf16x8, lo);
+      };
+      bf16x8 bh0, bl0;
+      build_B(0, bh0, bl0);
+      wg3_steps<0, NI>([&](auto ni_c) {
+        constexpr int ni = decltype(ni_c)::value;
+        const bf16x8 bh = bh0, bl = bl0;
+        if constexpr (ni + 1 < NI) {
+          if (a.dbg != 4 && a.dbg != 5) build_B(ni + 1, bh0, bl0);   // dbg 4 (timing only): one B fragment for all n-blocks
+        }
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
-    });
+        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bl, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], bh, acc[mi][ni], 0, 0, 0);
+      });
+    }
   };
   for (int seg = seg_lo; seg < seg_hi; seg += 2) {   // pairs, two barriers per pair (mirrors the producers)
     if (a.dbg != 3) compute(0);
@@ -640,15 +666,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <int MI, int NI>
-int launch_wgrad3p(const Wgrad3Args& a, hipStream_t st) {
+template <int MI, int NI, int SS>
+int launch_wgrad3p(const Wgrad3Args& a_in, hipStream_t st) {
   constexpr int MT = 16 * MI, NT = 64 * NI;
   constexpr int CIT = (NT + KK - 2) / KK + 1;
-  constexpr int BUF_BYTES = 2 * 4 * MT * 16 + ((CIT * PSX * 4 + 15) / 16) * 16;
+  constexpr int SEGP = 32 * SS, RWP = SEGP + KS - 1;
+  constexpr int PWSP = [] {
+    int v = RWP;
+    while (v % 32 != KS % 32) ++v;
+    return v;
+  }();
+  constexpr int BUF_BYTES = SS * 2 * 4 * MT * 16 + ((CIT * KS * PWSP * 4 + 15) / 16) * 16;
   size_t lds = (size_t)2 * BUF_BYTES;
+  Wgrad3Args a = a_in;
+  a.segs_x = (a.W + SEGP - 1) / SEGP;       // segments of 32*SS pixels
+  a.nseg = a.segs_x * a.H * a.B;
   dim3 grid((unsigned)a.nsplit, (unsigned)(a.n_pad / NT), (unsigned)(a.co_pad / MT));
-  if (int rc = nq_lds_optin<&conv_wgrad3p_kernel<MI, NI>>(lds)) return rc;
-  hipLaunchKernelGGL((conv_wgrad3p_kernel<MI, NI>), grid, dim3(512), lds, st, a);
+  if (int rc = nq_lds_optin<&conv_wgrad3p_kernel<MI, NI, SS>>(lds)) return rc;
+  hipLaunchKernelGGL((conv_wgrad3p_kernel<MI, NI, SS>), grid, dim3(512), lds, st, a);
   return nq_launch_status();
 }
 
@@ -686,30 +721,34 @@ extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, 
     const char* e = std::getenv("NQ_WG3_DBG");
     a.dbg = e ? atoi(e) : 0;
   }
-  if (pc) {   // producer / consumer variant (wide n-tiles only; the plan sized nsplit for one 8-wave workgroup per CU)
+  if (pc) {   // producer / consumer variant (wide n-tiles only; the plan sized nsplit for one 8-wave workgroup per CU);
+              // pc = number of 32-pixel k-steps per staged segment (1 or 2)
+#define NQ_WG3P(MI_, NI_)                                                                   \
+  return pc == 2 ? launch_wgrad3p<MI_, NI_, 2>(a, st) : launch_wgrad3p<MI_, NI_, 1>(a, st);
     if (ni_sel == 5) {
       switch (mi_sel) {
-        case 3: return launch_wgrad3p<3, 5>(a, st);
-        case 4: return launch_wgrad3p<4, 5>(a, st);
-        case 5: return launch_wgrad3p<5, 5>(a, st);
+        case 3: NQ_WG3P(3, 5)
+        case 4: NQ_WG3P(4, 5)
+        case 5: NQ_WG3P(5, 5)
         default: return NQ_ERR_UNSUPPORTED;
       }
     }
     if (ni_sel == 6) {
       switch (mi_sel) {
-        case 3: return launch_wgrad3p<3, 6>(a, st);
-        case 4: return launch_wgrad3p<4, 6>(a, st);
-        case 5: return launch_wgrad3p<5, 6>(a, st);
+        case 3: NQ_WG3P(3, 6)
+        case 4: NQ_WG3P(4, 6)
+        case 5: NQ_WG3P(5, 6)
         default: return NQ_ERR_UNSUPPORTED;
       }
     }
     if (ni_sel == 7) {
       switch (mi_sel) {
-        case 3: return launch_wgrad3p<3, 7>(a, st);
-        case 4: return launch_wgrad3p<4, 7>(a, st);
+        case 3: NQ_WG3P(3, 7)
+        case 4: NQ_WG3P(4, 7)
         default: return NQ_ERR_UNSUPPORTED;
       }
     }
+#undef NQ_WG3P
     return NQ_ERR_UNSUPPORTED;
   }
   if (ni_sel == 1) {

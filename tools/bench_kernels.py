@@ -66,9 +66,15 @@ def main():
                 r = wg("1")
                 os.environ["NQ_WG3_DBG"] = "0"
                 return r
-            var = {"4wave": lambda wg=wg: wg("0"), "prod/cons": lambda wg=wg: wg("1")}
+            def wgs1(wg=wg):
+                os.environ["NQ_WGRAD3_SS"] = "1"
+                r = wg("1")
+                os.environ["NQ_WGRAD3_SS"] = "0"
+                return r
+            var = {"4wave": lambda wg=wg: wg("0"), "pc seg32": wgs1, "prod/cons": lambda wg=wg: wg("1")}
             if os.environ.get("NQ_BENCH_DBG"):
-                var.update({"pc x1row": lambda wgd=wgd: wgd("1"), "pc noconv": lambda wgd=wgd: wgd("2"), "pc nomfma": lambda wgd=wgd: wgd("3")})
+                var.update({"pc x1row": lambda wgd=wgd: wgd("1"), "pc noconv": lambda wgd=wgd: wgd("2"), "pc nomfma": lambda wgd=wgd: wgd("3"),
+                            "pc oneB": lambda wgd=wgd: wgd("4"), "pc oneB+nc": lambda wgd=wgd: wgd("5")})
             cases.append((f"{name} wgrad3 {cin}x{cout}", flops, var))
     cases = [c for c in cases if args.only in c[0]]
     for name, flops, variants in cases:
