@@ -202,6 +202,13 @@ int nq_conv_wgrad3_supported(int B, int Cin, int H, int W, int Cout, int k);
 int64_t nq_conv_wgrad3_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
 int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                    int k, nq_stream_t stream);
+/* The same weight gradient dw (Cout,Cin,k,k) for a convolution with very FEW output channels (the 3-channel head, HNeRV.py:42)
+ * by exchanged operand roles: R[ci][(co,tap)] = sum_p x[ci][p] * dy[co][p+tap] is the weight gradient of the convolution
+ * dy -> x-channels and dW[co][ci][tap] = R[ci][co][k*k-1-tap]; the big tensor x is then the un-shifted GEMM operand read
+ * exactly once.  ws: nq_conv_wgrad3_ws_floats(B, Cout, H, W, Cin, k) floats (the exchanged problem).  No bias gradient
+ * (use nq_channel_sum on dy). */
+int nq_conv_wgrad3_swapped(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int H, int W, int Cout, int k,
+                           nq_stream_t stream);
 
 /* Weight + bias gradient of the same convolution: dw (Cout,Cin,k,k), db (Cout) (db may be NULL),
  * from x (B,Cin,H,W) and dy (B,Cout,H,W).  ws: scratch of >= nq_conv_wgrad_ws_floats(...) floats.

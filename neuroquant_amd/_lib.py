@@ -78,6 +78,7 @@ def _load():
     sig("nq_conv_wgrad3_supported", I, I, I, I, I, I, I)
     sig("nq_conv_wgrad3_ws_floats", L, I, I, I, I, I, I)
     sig("nq_conv_wgrad3", I, P, P, P, P, P, I, I, I, I, I, I, P)
+    sig("nq_conv_wgrad3_swapped", I, P, P, P, P, I, I, I, I, I, I, P)
     sig("nq_conv_wgrad_ws_floats", L, I, I, I, I, I, I)
     sig("nq_conv_wgrad", I, P, P, P, P, P, I, I, I, I, I, I, I, P)
     sig("nq_ps_gelu_backward", I, P, P, P, I, I, I, I, I, P)
@@ -94,7 +95,7 @@ EXPORTS = (
     "nq_adaround_init", "nq_adaround_forward", "nq_adaround_backward", "nq_reduce_ws_floats", "nq_round_loss", "nq_round_loss_backward",
     "nq_adam_step", "nq_adaround_forward_multi", "nq_adaround_backward_multi", "nq_adam_step_multi", "nq_step_prologue", "nq_adaround_backward_multi_dyn", "nq_adam_step_multi_dyn", "nq_fwht", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
     "nq_conv3_supported", "nq_conv3_weight_bytes", "nq_weight_layout3", "nq_weight_layout3_multi", "nq_conv_forward3_ws_floats", "nq_conv_forward3",
-    "nq_conv_wgrad3_supported", "nq_conv_wgrad3_ws_floats", "nq_conv_wgrad3",
+    "nq_conv_wgrad3_supported", "nq_conv_wgrad3_ws_floats", "nq_conv_wgrad3", "nq_conv_wgrad3_swapped",
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",
     "nq_channel_sum", "nq_frame_sse", "nq_gather_frames_u8",
 )

@@ -10,6 +10,8 @@ int nq_conv_igemm3_k5(const float*, const void*, const float*, float*, float*, c
 int nq_conv_splitk_finish(const float*, const float*, float*, float*, const float*, int, int, int, int, int, int, int, hipStream_t);
 int nq_conv3_nst_k3();
 int nq_conv3_nst_k5();
+int nq_conv3_nst8_k3();
+int nq_conv3_nst8_k5();
 int nq_conv_wgrad3_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int nq_conv_wgrad3_k5(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 }
@@ -38,6 +40,13 @@ inline int pick_mi3(int Cout) {
   return best;
 }
 inline int nst_of(int k) { return k == 5 ? nq_conv3_nst_k5() : nq_conv3_nst_k3(); }
+inline int nst8_of(int k) { return k == 5 ? nq_conv3_nst8_k5() : nq_conv3_nst8_k3(); }
+// the last 16-channel chunk holds <= 8 channels -> it is laid out (and run) as (1 octet x 4 taps) k-steps, see Conv3Args::tail8
+inline bool tail8_of(int Cin) { return Cin - CC * ((Cin + CC - 1) / CC - 1) <= 8; }
+inline int64_t total_steps3(int Cin, int k) {
+  const int nchunk = (Cin + CC - 1) / CC;
+  return tail8_of(Cin) ? (int64_t)(nchunk - 1) * nst_of(k) + nst8_of(k) : (int64_t)nchunk * nst_of(k);
+}
 
 // One thread per 16-byte fragment slot (c, s, tile, kq, co): 8 consecutive channels of one tap, split into bf16 hi/lo.
 // transposed = 0: logical conv == the stored conv, src(co, ch, tap) = w[co][ch][tap]
@@ -45,7 +54,7 @@ inline int nst_of(int k) { return k == 5 ? nq_conv3_nst_k5() : nq_conv3_nst_k3()
 struct WL3 {
   const float* w;
   uint4* out;
-  int Cin, Cout, KK, NST, nchunk, co_tiles, MT, transposed;
+  int Cin, Cout, KK, NST, NST8, nchunk, tail8, co_tiles, MT, transposed;
   int64_t slots;
 };
 __device__ __forceinline__ void wl3_slot(const WL3& p, int64_t i) {
@@ -54,9 +63,21 @@ __device__ __forceinline__ void wl3_slot(const WL3& p, int64_t i) {
   const int co_l = (int)(i % MT);
   const int kq = (int)((i / MT) % 4);
   const int tile = (int)((i / (4 * MT)) % co_tiles);
-  const int s = (int)((i / ((int64_t)4 * MT * co_tiles)) % NST);
-  const int c = (int)(i / ((int64_t)4 * MT * co_tiles * NST));
-  const int co = tile * MT + co_l, tap = 2 * s + (kq >> 1), ch0 = c * CC + (kq & 1) * 8;
+  // global k-step gs -> (chunk c, step s): full chunks have NST steps, a tail8 chunk (always the last) NST8
+  const int64_t gs = i / ((int64_t)4 * MT * co_tiles);
+  const int nfull = p.nchunk - p.tail8;
+  int c, s;
+  if (gs < (int64_t)nfull * NST) {
+    c = (int)(gs / NST);
+    s = (int)(gs - (int64_t)c * NST);
+  } else {
+    c = nfull;
+    s = (int)(gs - (int64_t)nfull * NST);
+  }
+  const bool t8 = p.tail8 && c == nfull;
+  const int co = tile * MT + co_l;
+  const int tap = t8 ? 4 * s + kq : 2 * s + (kq >> 1);
+  const int ch0 = t8 ? c * CC : c * CC + (kq & 1) * 8;
   unsigned hi[4], lo[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -75,7 +96,7 @@ __device__ __forceinline__ void wl3_slot(const WL3& p, int64_t i) {
     lo[j] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
   }
   // [c][s][plane][tile][kq][MT]
-  const int64_t step = (int64_t)c * NST + s;
+  const int64_t step = gs;
   const int64_t plane_stride = (int64_t)co_tiles * 4 * MT;
   const int64_t base = step * 2 * plane_stride + (int64_t)tile * 4 * MT + kq * MT + co_l;
   p.out[base] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
@@ -174,15 +195,27 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
       p.nsplit = ns_pc;
     }
   }
+  // narrow problems streaming a big tensor (the role-swapped head gradient: 3 x 9 n-values, K = all pixels): the 4-wave
+  // kernel runs 18 MFMAs per barrier with one 6 KB segment in flight per workgroup (latency-bound, 2.1 TB/s); the
+  // producer/consumer kernel with 128-pixel segments keeps 2 x 24 KB in flight per CU
+  if (wgrad3_pc_enabled() && p.ni == 1 && (p.mi == 2 || p.mi == 3) && tiles == 1 && W % 128 == 0) {
+    const int nseg_pc = (W / 128) * H * B;
+    if (nseg_pc / 256 >= 8) {
+      p.pc = 4;
+      p.nsplit = 256;
+    }
+  }
   return p;
 }
 
 // Fixed-order reduction of the split slabs: a workgroup owns 256/SG consecutive outputs, split group g adds slabs
 // g, g+SG, g+2SG, ... in order, and the SG partial sums are combined in LDS in index order -> run-to-run identical.
+// swap_kk > 0: the slabs hold R[co'][ci'][tap] of the ROLE-SWAPPED problem (x and dy exchanged); the result is written as
+// dW[ci'][co'][KK-1-tap], KK = swap_kk -- the weight gradient of the original convolution (ops.conv_wgrad_swapped3).
 template <int SG>
 __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ slab_db,
                                                             float* __restrict__ dw, float* __restrict__ db, int Cout, int N,
-                                                            int co_pad, int n_pad, int nsplit) {
+                                                            int co_pad, int n_pad, int nsplit, int swap_kk) {
   constexpr int OG = 256 / SG;
   __shared__ float part[SG][OG];
   const int o = threadIdx.x % OG, g = threadIdx.x / OG;
@@ -206,8 +239,17 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restr
     float t = part[0][o];
 #pragma unroll
     for (int j = 1; j < SG; ++j) t += part[j][o];
-    if (i < total) dw[i] = t;
-    else if (db && i < total + Cout) db[(int)(i - total)] = t;
+    if (i < total) {
+      if (swap_kk > 0) {
+        const int co = (int)(i / N), n = (int)(i - (int64_t)co * N);
+        const int ci = n / swap_kk, tap = n - ci * swap_kk;
+        dw[((int64_t)ci * Cout + co) * swap_kk + (swap_kk - 1 - tap)] = t;
+      } else {
+        dw[i] = t;
+      }
+    } else if (db && i < total + Cout) {
+      db[(int)(i - total)] = t;
+    }
   }
 }
 
@@ -233,7 +275,8 @@ int64_t nq_conv3_weight_bytes(int Cin, int Cout, int k) {
   if (!(k == 3 || k == 5)) return 0;
   const int mi = pick_mi3(Cout), mt = 16 * mi;
   const int64_t co_tiles = (Cout + mt - 1) / mt, nchunk = (Cin + CC - 1) / CC;
-  return nchunk * nst_of(k) * 2 * co_tiles * 4 * mt * 16;
+  (void)nchunk;
+  return total_steps3(Cin, k) * 2 * co_tiles * 4 * mt * 16;
 }
 
 // w: OIHW weight tensor of the STORED conv (Cout_w, Cin_w, k, k).  transposed = 0 -> operand of the forward conv
@@ -242,9 +285,10 @@ static bool wl3_fill(WL3& p, const float* w, void* wt3, int Cin, int Cout, int k
   if (!w || !wt3 || !(k == 3 || k == 5) || Cin <= 0 || Cout <= 0) return false;
   const int mi = pick_mi3(Cout);
   p.w = w; p.out = reinterpret_cast<uint4*>(wt3);
-  p.Cin = Cin; p.Cout = Cout; p.KK = k * k; p.NST = nst_of(k);
+  p.Cin = Cin; p.Cout = Cout; p.KK = k * k; p.NST = nst_of(k); p.NST8 = nst8_of(k);
   p.MT = 16 * mi; p.co_tiles = (Cout + p.MT - 1) / p.MT; p.nchunk = (Cin + CC - 1) / CC; p.transposed = transposed;
-  p.slots = (int64_t)p.nchunk * p.NST * p.co_tiles * 4 * p.MT;
+  p.tail8 = tail8_of(Cin) ? 1 : 0;
+  p.slots = total_steps3(Cin, k) * p.co_tiles * 4 * p.MT;
   return true;
 }
 
@@ -301,8 +345,22 @@ int64_t nq_conv_wgrad3_ws_floats(int B, int Cin, int H, int W, int Cout, int k) 
   return (int64_t)p.nsplit * p.co_pad * ((int64_t)p.n_pad + 1);
 }
 
+static int conv_wgrad3_impl(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W,
+                            int Cout, int k, int swap_kk, nq_stream_t stream);
+
 int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                    int k, nq_stream_t stream) {
+  return conv_wgrad3_impl(x, dy, dw, db, ws, B, Cin, H, W, Cout, k, 0, stream);
+}
+
+int nq_conv_wgrad3_swapped(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int H, int W, int Cout, int k,
+                           nq_stream_t stream) {
+  // the kernel sees the exchanged problem: "x" = dy (Cout channels), "dy" = x (Cin channels)
+  return conv_wgrad3_impl(dy, x, dw, nullptr, ws, B, Cout, H, W, Cin, k, k * k, stream);
+}
+
+static int conv_wgrad3_impl(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W,
+                            int Cout, int k, int swap_kk, nq_stream_t stream) {
   if (!x || !dy || !dw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
   if (!(k == 3 || k == 5)) return NQ_ERR_UNSUPPORTED;
   if ((int64_t)Cout * H * W >= (1ll << 31) || (int64_t)Cin * H * W >= (1ll << 31)) return NQ_ERR_UNSUPPORTED;
@@ -317,10 +375,10 @@ int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float*
   int64_t total = (int64_t)Cout * N + Cout;
   if (total < 65536 && p.nsplit >= 16) {
     hipLaunchKernelGGL(wgrad3_reduce_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, slab, slab_db, dw, db,
-                       Cout, N, p.co_pad, p.n_pad, p.nsplit);
+                       Cout, N, p.co_pad, p.n_pad, p.nsplit, swap_kk);
   } else {
     hipLaunchKernelGGL(wgrad3_reduce_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, slab, slab_db, dw, db,
-                       Cout, N, p.co_pad, p.n_pad, p.nsplit);
+                       Cout, N, p.co_pad, p.n_pad, p.nsplit, swap_kk);
   }
   return nq_launch_status();
 }

@@ -25,7 +25,10 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
                                                        const float* __restrict__ bias, float* __restrict__ y, int Cin,
                                                        int H, int W, int CO, int epi, int tiles_x) {
   constexpr int KK = KS * KS, PAD = KS / 2;
-  constexpr int TH = 16, TW = 64, CCH = 4;
+#ifndef NQ_HEAD_CCH
+#define NQ_HEAD_CCH 4
+#endif
+  constexpr int TH = 16, TW = 64, CCH = NQ_HEAD_CCH;
   constexpr int PH = TH + KS - 1;
   // LDS rows: [OFF-PAD, OFF) left halo | [OFF, OFF+64) interior (16-byte aligned) | [OFF+64, OFF+64+PAD) right halo.
   // The interior is staged with 16-byte global loads / ds_write_b128 (4.5 per thread per chunk instead of 18 scalar

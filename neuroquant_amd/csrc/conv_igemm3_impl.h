@@ -49,6 +49,8 @@ struct Conv3Args {
   int nsplit, per_split;  // split-K over channel chunks: blockIdx.z = b*nsplit + split, chunks [split*per, +per)
   float* slab;            // [nsplit][B][Cout][H][W] raw partial sums when nsplit > 1 (nq_conv_splitk_finish adds them)
   int lds_epi;            // the launch reserved MT*1024 B of LDS: the data-gradient epilogue may transpose through it
+  int tail8;              // the LAST channel chunk holds <= 8 channels: it runs NST8 k-steps of (1 octet x 4 taps) instead of
+                          // NST steps of (2 octets x 2 taps) -- 7 instead of 13 steps for k = 5 (no MFMAs on an all-zero octet)
 };
 
 constexpr int KS = NQ_KS;
@@ -59,6 +61,7 @@ constexpr int PH = TH + KS - 1, PW = TW + KS - 1;
 constexpr int NPIX = PH * PW;
 constexpr int PP = (NPIX + 15) / 16 * 16;  // octet-plane stride in pixels (16-byte units): multiple of 256 B
 constexpr int NST = (KK + 1) / 2;          // k-steps per channel chunk
+constexpr int NST8 = (KK + 3) / 4;         // k-steps of a tail chunk of <= 8 channels (lane group kq -> tap 4*step + kq)
 constexpr int CC = 16;                     // channels per chunk
 constexpr int PATCH_U4 = 2 * 2 * PP;       // 16-byte units per patch buffer: [plane][octet][PP]
 constexpr int NITEM = 2 * NPIX;            // staging items (octet, pixel)
@@ -187,7 +190,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // ---- prologue: step 0 -> LDS buffer 0 (via set A), step 1 in flight in set B ----
   const int nchunk = min(a.per_split, a.nchunk - c_lo);
-  const int G = nchunk * NST;
+  const bool tail = a.tail8 && (c_lo + nchunk == a.nchunk);   // this split ends with the short tail chunk
+  const int nfull = nchunk - (tail ? 1 : 0);
+  const int G = nfull * NST + (tail ? NST8 : 0);
   NQ3_LOAD_PATCH(0)
   NQ3_LOAD_W(wvA, 0)
   if (G > 1) {
@@ -199,10 +204,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // one chunk; PAR = parity of its first global step: LDS buffer (g&1) holds step g, register set B/A ((g+1)&1 = 1/0)
   // holds step g+1, the loads of step g+2 are issued into the other set at the start of step g
-  auto run_chunk = [&](auto par_c, int ch) {
+  auto run_chunk = [&](auto par_c, auto tail_c, int ch) {
     constexpr int PAR = decltype(par_c)::value;
-    const int g0 = ch * NST;
-    steps3<0, NST>([&](auto st_c) {
+    constexpr bool TAIL = decltype(tail_c)::value != 0;
+    constexpr int NSTC = TAIL ? NST8 : NST;
+    const int g0 = ch * NST;   // every chunk in front of this one is a full chunk
+    steps3<0, NSTC>([&](auto st_c) {
       constexpr int st = decltype(st_c)::value;
       constexpr int gp = (PAR + st) & 1;  // parity of the global step
       const int g = g0 + st;
@@ -213,16 +220,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           NQ3_LOAD_W(wvB, g + 2)
         }
       }
-      constexpr int pst = (NST >= 3) ? NST - 3 : 0;
-      if constexpr (st == pst) {
-        if (ch + 1 < nchunk) {
-          NQ3_LOAD_PATCH(ch + 1)
+      if constexpr (!TAIL) {
+        constexpr int pst = (NST >= 3) ? NST - 3 : 0;
+        if constexpr (st == pst) {
+          if (ch + 1 < nchunk) {
+            NQ3_LOAD_PATCH(ch + 1)
+          }
         }
       }
-      // taps of this step: even lane groups -> tap 2*st, odd -> tap 2*st+1 (clamped; its weights are zero when padded)
-      constexpr int te = 2 * st, to_ = (2 * st + 1 < KK) ? 2 * st + 1 : KK - 1;
-      constexpr int off_e = (te / KS) * PW + (te % KS), off_o = (to_ / KS) * PW + (to_ % KS);
-      const u32x4* __restrict__ pbt = pb + (odd_tap ? off_o : off_e);
+      const u32x4* __restrict__ pbt;
+      if constexpr (TAIL) {
+        // one octet, four taps: lane group kq -> tap 4*st + kq (clamped; its weights are zero when padded)
+        constexpr int t0 = 4 * st;
+        constexpr int ta = t0 < KK ? t0 : KK - 1, tb = t0 + 1 < KK ? t0 + 1 : KK - 1, tc = t0 + 2 < KK ? t0 + 2 : KK - 1,
+                      td = t0 + 3 < KK ? t0 + 3 : KK - 1;
+        constexpr int oa = (ta / KS) * PW + (ta % KS), ob = (tb / KS) * PW + (tb % KS), oc = (tc / KS) * PW + (tc % KS),
+                      od = (td / KS) * PW + (td % KS);
+        const int off = (kq == 0) ? oa : (kq == 1) ? ob : (kq == 2) ? oc : od;
+        pbt = patch0 + (2 * wave) * PW + l16 + off;
+      } else {
+        // taps of this step: even lane groups -> tap 2*st, odd -> tap 2*st+1 (clamped; its weights are zero when padded)
+        constexpr int te = 2 * st, to_ = (2 * st + 1 < KK) ? 2 * st + 1 : KK - 1;
+        constexpr int off_e = (te / KS) * PW + (te % KS), off_o = (to_ / KS) * PW + (to_ % KS);
+        pbt = pb + (odd_tap ? off_o : off_e);
+      }
       const u32x4* __restrict__ wb = wl0 + gp * W_U4 + a_lane;
       bf16x8 bh[4], bl[4];
 #pragma unroll
@@ -262,7 +283,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           __builtin_amdgcn_sched_barrier(0);
         }
       });
-      if constexpr (st == NST - 1) {
+      if constexpr (!TAIL && st == NST - 1) {
         if (ch + 1 < nchunk) {
           __syncthreads();  // every wave is done with the current patch
           NQ3_STORE_PATCH(patch0)
@@ -271,9 +292,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       __syncthreads();
     });
   };
-  for (int ch = 0; ch < nchunk; ch += 2) {
-    run_chunk(std::integral_constant<int, 0>{}, ch);
-    if (ch + 1 < nchunk) run_chunk(std::integral_constant<int, (NST & 1)>{}, ch + 1);
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  for (int ch = 0; ch < nfull; ch += 2) {
+    run_chunk(C0{}, C0{}, ch);
+    if (ch + 1 < nfull) run_chunk(std::integral_constant<int, (NST & 1)>{}, C0{}, ch + 1);
+  }
+  if (tail) {   // parity of its first global step = parity of nfull * NST
+    if ((nfull & 1) && (NST & 1)) run_chunk(C1{}, C1{}, nfull);
+    else run_chunk(C0{}, C1{}, nfull);
   }
 #undef NQ3_LOAD_PATCH
 #undef NQ3_STORE_PATCH
@@ -513,6 +540,7 @@ extern "C" int NQ_CAT(nq_conv_igemm3_k, NQ_KS)(const float* x, const void* wt3, 
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.r = r; a.epi = epi;
   a.tiles_x = (W + TW - 1) / TW;
   a.nchunk = (Cin + CC - 1) / CC;
+  a.tail8 = (Cin - CC * (a.nchunk - 1)) <= 8 ? 1 : 0;
   a.co_tiles = (Cout + 16 * mi_sel - 1) / (16 * mi_sel);
   const int tiles = a.tiles_x * ((H + TH - 1) / TH);
   switch (mi_sel) {
@@ -527,3 +555,4 @@ extern "C" int NQ_CAT(nq_conv_igemm3_k, NQ_KS)(const float* x, const void* wt3, 
 
 // steps per chunk for this kernel size (used by nq_weight_layout3)
 extern "C" int NQ_CAT(nq_conv3_nst_k, NQ_KS)() { return NST; }
+extern "C" int NQ_CAT(nq_conv3_nst8_k, NQ_KS)() { return NST8; }

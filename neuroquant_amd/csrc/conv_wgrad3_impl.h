@@ -725,6 +725,14 @@ extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, 
               // pc = number of 32-pixel k-steps per staged segment (1 or 2)
 #define NQ_WG3P(MI_, NI_)                                                                   \
   return pc == 2 ? launch_wgrad3p<MI_, NI_, 2>(a, st) : launch_wgrad3p<MI_, NI_, 1>(a, st);
+    if (ni_sel == 1) {   // narrow problems (the role-swapped head gradient): 128-pixel segments keep enough bytes in flight
+      if (pc != 4) return NQ_ERR_UNSUPPORTED;
+      switch (mi_sel) {
+        case 2: return launch_wgrad3p<2, 1, 4>(a, st);
+        case 3: return launch_wgrad3p<3, 1, 4>(a, st);
+        default: return NQ_ERR_UNSUPPORTED;
+      }
+    }
     if (ni_sel == 5) {
       switch (mi_sel) {
         case 3: NQ_WG3P(3, 5)

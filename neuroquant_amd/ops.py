@@ -482,16 +482,20 @@ def conv_wgrad_swapped3(x, dy, cout, k, want_db, out=None):
     dW[co][ci][kh][kw] = R[ci][co][K-1-kh][K-1-kw].  The big tensor (x, 242 MB) is then the un-shifted GEMM operand
     read exactly once, only the 3-channel dy needs halo rows, and the MFMA tile is 37(->48) x 27(->64) instead of
     3(->16) x 333(->384)."""
-    cin = x.shape[1]
-    r, _ = conv_wgrad3_raw(dy, x, cin, k, False)
-    dw = r.permute(1, 0, 2, 3).flip(2, 3)
-    db = channel_sum(dy) if want_db else None
-    if out is None:
-        return dw.contiguous(), db
-    out[0].copy_(dw)
+    B, cin, H, W = x.shape
+    ws = torch.empty(L.lib().nq_conv_wgrad3_ws_floats(B, cout, H, W, cin, k), device=x.device, dtype=torch.float32)
+    dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32) if out is None else out[0]
+    # the slab reduction writes dW[co][ci][K-1-kh][K-1-kw] directly (no permute / flip / copy passes)
+    _timed(("conv_wgrad3", k, cout, cin, H, W, B, 0),
+           lambda: L.check(L.lib().nq_conv_wgrad3_swapped(_p(x), _p(dy), _p(dw), _p(ws), B, cin, H, W, cout, k, _stream()),
+                           "conv_wgrad3_swapped"))
+    db = None
     if want_db:
-        out[1].copy_(db)
-    return out[0], (out[1] if want_db else None)
+        db = channel_sum(dy)
+        if out is not None:
+            out[1].copy_(db)
+            db = out[1]
+    return dw, db
 
 
 def conv_wgrad_raw(x, dy, cout, k, want_db, x_gelu=False, out=None):

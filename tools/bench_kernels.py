@@ -76,6 +76,17 @@ def main():
                 var.update({"pc x1row": lambda wgd=wgd: wgd("1"), "pc noconv": lambda wgd=wgd: wgd("2"), "pc nomfma": lambda wgd=wgd: wgd("3"),
                             "pc oneB": lambda wgd=wgd: wgd("4"), "pc oneB+nc": lambda wgd=wgd: wgd("5")})
             cases.append((f"{name} wgrad3 {cin}x{cout}", flops, var))
+    # head layer 37 -> 3, k3, 640x1280 (streaming VALU kernels)
+    hx = torch.randn(2, 37, 640, 1280, generator=g).cuda()
+    hw = (torch.randn(3, 37, 3, 3, generator=g) / math.sqrt(37 * 9)).cuda()
+    hb = torch.zeros(3).cuda()
+    hdy = torch.randn(2, 3, 640, 1280, generator=g).cuda()
+    hz = torch.rand(2, 37, 640, 1280, generator=g).cuda()
+    hwt, hdims, hwb, hdims_b = ops.weight_layouts(hw, True)
+    hfl = 2.0 * 2 * 3 * 37 * 9 * 640 * 1280
+    cases.append(("head fwd 37->3", hfl, {"": lambda: ops.conv_forward_raw(hx, hwt, hdims, hb, 3, 3, ops.EPI_TANH, 1)}))
+    cases.append(("head dgrad 3->37", hfl, {"": lambda: ops.conv_forward_raw(hdy, hwb, hdims_b, None, 37, 3, ops.EPI_DGRAD_GELU, 2, zprev=hz)}))
+    cases.append(("head wgrad 37x3", hfl, {"": lambda: ops.conv_wgrad_swapped3(hx, hdy, 3, 3, True)}))
     cases = [c for c in cases if args.only in c[0]]
     for name, flops, variants in cases:
         for fn in variants.values():
