@@ -95,7 +95,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
   u32x4* const patch0 = smem;                  // 1 buffer of PATCH_U4 (re-filled between two barriers per chunk)
-  u32x4* const wl0 = smem + PATCH_U4;          // 2 buffers of W_U4
+  // R4: ring of 4 weight buffers with one barrier per TWO k-steps (measured in one process, per-step barrier -> ring: the
+  // 80-channel tile -10 %, the 48/64-channel tiles +2..3 % -- so only MI = 5 takes it); else 2 buffers, barrier per step
+  constexpr bool R4 = (MI >= 5);
+  constexpr int WMASK = R4 ? 3 : 1;
+  u32x4* const wl0 = smem + PATCH_U4;          // weight buffers of W_U4: k-step g lives in buffer g & WMASK
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
@@ -200,10 +204,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   NQ3_STORE_PATCH(patch0)
   NQ3_STORE_W(wvA, wl0)
+  if constexpr (R4) {
+    if (G > 1) {
+      NQ3_STORE_W(wvB, wl0 + W_U4)
+    }
+    if (G > 2) {
+      NQ3_LOAD_W(wvA, 2)
+    }
+    if (G > 3) {
+      NQ3_LOAD_W(wvB, 3)
+    }
+  }
   __syncthreads();
 
-  // one chunk; PAR = parity of its first global step: LDS buffer (g&1) holds step g, register set B/A ((g+1)&1 = 1/0)
-  // holds step g+1, the loads of step g+2 are issued into the other set at the start of step g
+  // Weight pipeline, R4: k-step g reads LDS buffer g & 3.  During step g (in the middle of its MFMA block) register set g & 1,
+  // which holds the weights of step g+2 (loaded two steps ago), is published into buffer (g+2) & 3 and re-armed with the
+  // loads of step g+4.  With a ring of FOUR buffers one barrier per TWO k-steps is enough: a barrier follows every odd
+  // step of a chunk (and its last step), which always puts one between the publication of a buffer (step g-2) and its use
+  // (step g), and one between the last reads of a buffer (step g-4) and its re-publication (step g-2).
+  // !R4: LDS buffer g & 1 holds step g, register set (g+1) & 1 holds step g+1 and is published during step g, the loads of
+  // step g+2 are issued into the other set at the start of step g; a barrier after every step.
+  // one chunk; PAR = parity of its first global step
   auto run_chunk = [&](auto par_c, auto tail_c, int ch) {
     constexpr int PAR = decltype(par_c)::value;
     constexpr bool TAIL = decltype(tail_c)::value != 0;
@@ -213,11 +234,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr int st = decltype(st_c)::value;
       constexpr int gp = (PAR + st) & 1;  // parity of the global step
       const int g = g0 + st;
-      if (g + 2 < G) {
-        if constexpr (gp == 0) {
-          NQ3_LOAD_W(wvA, g + 2)
-        } else {
-          NQ3_LOAD_W(wvB, g + 2)
+      if constexpr (!R4) {
+        if (g + 2 < G) {
+          if constexpr (gp == 0) {
+            NQ3_LOAD_W(wvA, g + 2)
+          } else {
+            NQ3_LOAD_W(wvB, g + 2)
+          }
         }
       }
       if constexpr (!TAIL) {
@@ -244,7 +267,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr int off_e = (te / KS) * PW + (te % KS), off_o = (to_ / KS) * PW + (to_ % KS);
         pbt = pb + (odd_tap ? off_o : off_e);
       }
-      const u32x4* __restrict__ wb = wl0 + gp * W_U4 + a_lane;
+      const u32x4* __restrict__ wb = wl0 + (g & WMASK) * W_U4 + a_lane;
       bf16x8 bh[4], bl[4];
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
@@ -269,15 +292,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nb], acc[mi][nb], 0, 0, 0);
         if constexpr (mi == (MI - 1) / 2) {
-          // publish step g+1 (loaded one step ago) into the other LDS buffer -- in the MIDDLE of the MFMA block, so the
-          // LDS write latency is covered by the remaining MFMAs instead of sitting in front of the barrier (that buffer
-          // was last read in step g-1, which every wave left through the previous barrier)
-          if (g + 1 < G) {
-            u32x4* wdst = wl0 + (gp ^ 1) * W_U4;
-            if constexpr (gp == 0) {
-              NQ3_STORE_W(wvB, wdst)
-            } else {
-              NQ3_STORE_W(wvA, wdst)
+          // publish the next weights in the MIDDLE of the MFMA block (the LDS write latency is covered by the remaining
+          // MFMAs instead of sitting in front of the barrier)
+          if constexpr (R4) {   // step g+2 from set g & 1, which is then re-armed with the loads of step g+4
+            if (g + 2 < G) {
+              u32x4* wdst = wl0 + ((g + 2) & 3) * W_U4;
+              if constexpr (gp == 0) {
+                NQ3_STORE_W(wvA, wdst)
+              } else {
+                NQ3_STORE_W(wvB, wdst)
+              }
+            }
+            if (g + 4 < G) {
+              if constexpr (gp == 0) {
+                NQ3_LOAD_W(wvA, g + 4)
+              } else {
+                NQ3_LOAD_W(wvB, g + 4)
+              }
+            }
+          } else {              // step g+1 (loaded one step ago) from set (g+1) & 1
+            if (g + 1 < G) {
+              u32x4* wdst = wl0 + (gp ^ 1) * W_U4;
+              if constexpr (gp == 0) {
+                NQ3_STORE_W(wvB, wdst)
+              } else {
+                NQ3_STORE_W(wvA, wdst)
+              }
             }
           }
           __builtin_amdgcn_sched_barrier(0);
@@ -289,7 +329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           NQ3_STORE_PATCH(patch0)
         }
       }
-      __syncthreads();
+      if constexpr (!R4 || (st & 1) != 0 || st == NSTC - 1) __syncthreads();
     });
   };
   using C0 = std::integral_constant<int, 0>;
@@ -513,7 +553,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int MI>
 int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
   constexpr int MT = 16 * MI;
-  size_t lds = (size_t)(PATCH_U4 + 2 * 2 * 4 * MT) * 16;
+  size_t lds = (size_t)(PATCH_U4 + (MI >= 5 ? 4 : 2) * 2 * 4 * MT) * 16;   // patch + weight buffers (ring of 4 for MI = 5)
   Conv3Args a = a_in;
   a.lds_epi = 0;
   if (a.epi == NQ_EPI_DGRAD_GELU && a.nsplit == 1 && MI <= 4) {   // 4 waves x [MT][64] floats for the wide epilogue
