@@ -267,6 +267,7 @@ struct AdaSegD {
   int64_t n;
   int row_len, per_row, soft;
   float qmax, reg_weight;
+  int vec;  // every pointer of the segment is 16-byte aligned -> 16-byte accesses
 };
 struct AdaMulti {
   AdaSegD s[MAXSEG];
@@ -281,6 +282,7 @@ struct AdamSegD {
   float* m;
   float* v;
   int64_t n;
+  int vec;
 };
 struct AdamMulti {
   AdamSegD s[MAXSEG];
@@ -295,25 +297,57 @@ __device__ __forceinline__ int find_seg(const T& t, int blk) {
   return k;
 }
 
+// A thread owns 4 CONSECUTIVE elements (one 16-byte load / store per tensor when the segment's pointers are 16-byte
+// aligned: these kernels are bound by the number of memory instructions, 23 -> 10 us for the 2.65 M elements of HNeRV-3M);
+// per-element arithmetic unchanged.
 template <bool BWD>
 __global__ __launch_bounds__(TPB) void adaround_multi_kernel(AdaMulti t) {
   const int k = find_seg(t, blockIdx.x);
   const AdaSegD& sg = t.s[k];
-  int64_t i = (int64_t)(blockIdx.x - t.blk0[k]) * (TPB * EPT) + threadIdx.x;
-#pragma unroll
-  for (int e = 0; e < EPT; ++e, i += TPB) {
-    if (i < sg.n) {
-      const int64_t row = sg.per_row ? i / sg.row_len : 0;
-      const float d = sg.delta[row], z = sg.zp[row];
-      if (BWD) {
-        const float rb = t.dyn ? t.dyn[0] : t.reg_b;
-        const float rw = t.dyn ? sg.reg_weight * t.dyn[1] : sg.reg_weight;   // gate is exactly 0 or 1
-        sg.out[i] = ada_bwd_elem(sg.x[i], sg.gy[i], sg.alpha[i], d, z, sg.qmax, rw, rb);
-      } else {
-        float xq;
-        sg.out[i] = ada_fwd_elem(sg.x[i], sg.alpha[i], d, z, sg.qmax, sg.soft, xq);
-      }
+  const int64_t i0 = (int64_t)(blockIdx.x - t.blk0[k]) * (TPB * EPT) + 4 * threadIdx.x;
+  if (i0 >= sg.n) return;
+  const bool vec = sg.vec && (i0 + 3 < sg.n);
+  float xv[4], av[4], gv[4] = {0.f, 0.f, 0.f, 0.f}, ov[4];
+  if (vec) {
+    const float4 x4 = *reinterpret_cast<const float4*>(sg.x + i0), a4 = *reinterpret_cast<const float4*>(sg.alpha + i0);
+    xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+    av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
+    if (BWD) {
+      const float4 g4 = *reinterpret_cast<const float4*>(sg.gy + i0);
+      gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
     }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool in = i0 + j < sg.n;
+      xv[j] = in ? sg.x[i0 + j] : 0.f;
+      av[j] = in ? sg.alpha[i0 + j] : 0.f;
+      if (BWD) gv[j] = in ? sg.gy[i0 + j] : 0.f;
+    }
+  }
+  const int64_t row0 = sg.per_row ? i0 / sg.row_len : 0;
+  const int rem0 = sg.per_row ? (int)(i0 - row0 * sg.row_len) : 0;
+  const float rb = (BWD && t.dyn) ? t.dyn[0] : t.reg_b;
+  const float rw = (BWD && t.dyn) ? sg.reg_weight * t.dyn[1] : sg.reg_weight;   // gate is exactly 0 or 1
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int64_t row = 0;
+    if (sg.per_row) row = (sg.row_len >= 4) ? row0 + ((rem0 + j >= sg.row_len) ? 1 : 0) : (i0 + j) / sg.row_len;
+    if (i0 + j >= sg.n) row = 0;
+    const float d = sg.delta[row], z = sg.zp[row];
+    if (BWD) {
+      ov[j] = ada_bwd_elem(xv[j], gv[j], av[j], d, z, sg.qmax, rw, rb);
+    } else {
+      float xq;
+      ov[j] = ada_fwd_elem(xv[j], av[j], d, z, sg.qmax, sg.soft, xq);
+    }
+  }
+  if (vec) {
+    *reinterpret_cast<float4*>(sg.out + i0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i0 + j < sg.n) sg.out[i0 + j] = ov[j];
   }
 }
 
@@ -325,10 +359,29 @@ __global__ __launch_bounds__(TPB) void adam_multi_kernel(AdamMulti t, float step
   }
   const int k = find_seg(t, blockIdx.x);
   const AdamSegD& sg = t.s[k];
-  int64_t i = (int64_t)(blockIdx.x - t.blk0[k]) * (TPB * EPT) + threadIdx.x;
+  const int64_t i0 = (int64_t)(blockIdx.x - t.blk0[k]) * (TPB * EPT) + 4 * threadIdx.x;
+  if (i0 >= sg.n) return;
+  if (sg.vec && i0 + 3 < sg.n) {   // same per-element arithmetic as adam_elem, four elements per 16-byte access
+    const float4 g4 = *reinterpret_cast<const float4*>(sg.g + i0);
+    float4 m4 = *reinterpret_cast<const float4*>(sg.m + i0), v4 = *reinterpret_cast<const float4*>(sg.v + i0);
+    float4 p4 = *reinterpret_cast<const float4*>(sg.p + i0);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    float m[4] = {m4.x, m4.y, m4.z, m4.w}, v[4] = {v4.x, v4.y, v4.z, v4.w}, p[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
-  for (int e = 0; e < EPT; ++e, i += TPB)
-    if (i < sg.n) adam_elem(sg.p, sg.g, sg.m, sg.v, i, step_size, beta1, beta2, eps, bc2_sqrt);
+    for (int j = 0; j < 4; ++j) {
+      m[j] = m[j] + (1.f - beta1) * (g[j] - m[j]);
+      v[j] = v[j] * beta2 + (1.f - beta2) * (g[j] * g[j]);
+      const float denom = sqrtf(v[j]) / bc2_sqrt + eps;
+      p[j] = p[j] - step_size * (m[j] / denom);
+    }
+    *reinterpret_cast<float4*>(sg.m + i0) = make_float4(m[0], m[1], m[2], m[3]);
+    *reinterpret_cast<float4*>(sg.v + i0) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(sg.p + i0) = make_float4(p[0], p[1], p[2], p[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i0 + j < sg.n) adam_elem(sg.p, sg.g, sg.m, sg.v, i0 + j, step_size, beta1, beta2, eps, bc2_sqrt);
+  }
 }
 
 inline unsigned blocks_per_row(int64_t row_len) { return (unsigned)((row_len + TPB * EPT - 1) / (TPB * EPT)); }
@@ -469,6 +522,7 @@ static int ada_multi(const nq_ada_seg* segs, int nseg, float reg_b, const float*
       d.x = h.x; d.gy = h.gy; d.alpha = h.alpha; d.delta = h.delta; d.zp = h.zp; d.out = h.out;
       d.n = h.rows * h.row_len; d.row_len = (int)h.row_len; d.per_row = h.per_row; d.soft = h.soft;
       d.qmax = (float)(h.n_levels - 1); d.reg_weight = h.reg_weight;
+      d.vec = (((uintptr_t)h.x | (uintptr_t)h.alpha | (uintptr_t)h.out | (uintptr_t)(bwd ? h.gy : h.x)) & 15) == 0;
       t.blk0[k] = blocks;
       blocks += (int)((d.n + TPB * EPT - 1) / (TPB * EPT));
     }
@@ -526,6 +580,7 @@ static int adam_multi(const nq_adam_seg* segs, int nseg, float step_size, float 
       const nq_adam_seg& h = segs[base + k];
       if (!h.p || !h.g || !h.m || !h.v || h.n <= 0) return NQ_ERR_INVALID;
       t.s[k].p = h.p; t.s[k].g = h.g; t.s[k].m = h.m; t.s[k].v = h.v; t.s[k].n = h.n;
+      t.s[k].vec = (((uintptr_t)h.p | (uintptr_t)h.g | (uintptr_t)h.m | (uintptr_t)h.v) & 15) == 0;
       t.blk0[k] = blocks;
       blocks += (int)((h.n + TPB * EPT - 1) / (TPB * EPT));
     }

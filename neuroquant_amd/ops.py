@@ -775,16 +775,18 @@ class _DecoderStackFn(Function):
             b = _dev(wb[2 * l + 1], "bias") if wb[2 * l + 1] is not None else None
             cout, cin = W.shape[0], W.shape[1]
             use3, use3_bwd, i_f, i_b = plan[l]
+            # layer 0's data-gradient operand is only needed when the embedding itself is trained (FP32 trainer: the
+            # ConvNeXt encoder sits below it, reference regress.py:259-266)
+            need_b = (l > 0 and not use3_bwd) or (l == 0 and ctx.needs_input_grad[0])
+            wt = dims = wbk = dims_b = None
             if use3:
                 wt3 = operands[i_f]
-                wt, dims = None, None
+                if need_b:
+                    _, _, wbk, dims_b = weight_layouts(W, need_bwd=True)
+            elif need_b:   # both fp32 operands of this layer from ONE launch
+                wt, dims, wbk, dims_b = weight_layouts(W, need_bwd=True)
             else:
                 wt, dims, _, _ = weight_layouts(W, need_bwd=False)
-            wbk = dims_b = None
-            if (l > 0 and not use3_bwd) or (l == 0 and ctx.needs_input_grad[0]):
-                # layer 0's data-gradient operand is only needed when the embedding itself is trained (FP32 trainer:
-                # the ConvNeXt encoder sits below it, reference regress.py:259-266)
-                _, _, wbk, dims_b = weight_layouts(W, need_bwd=True)
             last = l == n - 1
             if last:
                 epi = EPI_TANH if spec.tanh_out else EPI_PLAIN
