@@ -187,11 +187,17 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
   p.pc = 0;
   // producer/consumer kernel (8 waves, ONE workgroup per CU): wide tiles with a long K loop per workgroup
   if (wgrad3_pc_enabled() && p.ni >= 5 && p.mi >= 3 && tiles <= 256) {
-    const int ss = (W % 64 == 0 && !wgrad3_ss1()) ? 2 : 1;   // 64-pixel segments where rows divide evenly
-    const int nseg_pc = ((W + 32 * ss - 1) / (32 * ss)) * H * B;
+    // rows per staged segment: 4 (2) where H divides and every workgroup still gets >= 16 segments; NQ_WGRAD3_SS=1 -> 1
+    int sy = 1;
     int ns_pc = 256 / tiles;
-    if (ns_pc >= 1 && nseg_pc / ns_pc >= 8 * (3 - ss)) {
-      p.pc = ss;
+    const int segs_x = (W + 31) / 32;
+    if (!wgrad3_ss1() && ns_pc >= 1) {
+      if (H % 4 == 0 && segs_x * (H / 4) * B / ns_pc >= 16) sy = 4;
+      else if (H % 2 == 0 && segs_x * (H / 2) * B / ns_pc >= 16) sy = 2;
+    }
+    const int nseg_pc = segs_x * (H / sy) * B;
+    if (ns_pc >= 1 && nseg_pc / ns_pc >= 16) {
+      p.pc = sy == 1 ? 1 : 10 + sy;
       p.nsplit = ns_pc;
     }
   }

@@ -350,12 +350,14 @@ constexpr int ni3_for(int mi) { return mi <= 3 ? 6 : (mi <= 4 ? 6 : 6); }
 // slots the consumer's MFMAs leave free (an MFMA holds the SIMD's vector issue for 8 of its 16 cycles) instead of
 // standing in front of them in one in-order stream.  Same LDS images, same arithmetic, same slab layout as above: results
 // are bit-identical for an equal split plan.  One barrier per segment, executed by all eight waves.
-template <int MI, int NI, int SS>
+template <int MI, int NI, int SS, int SY>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad3p_kernel(Wgrad3Args a) {
-  // SS = 32-pixel MFMA k-steps per staged segment (segment = 32*SS pixels of one image row, one barrier each): SS = 2
-  // halves the barriers and the consumers' start-up (first fragments after a barrier) per MFMA where rows are a
-  // multiple of 64 pixels
+  // A staged segment = SY image rows x 32*SS pixels = SS*SY MFMA k-steps of 32 pixels, one barrier each.
+  //   SY > 1 (rows): the KS-row x halo is shared -- KS+SY-1 rows are staged for SY row-steps instead of KS per step
+  //   (SY = 4: 2 rows per step instead of 5, the producers' x work and the x traffic drop by 60 %);
+  //   SS > 1 (columns): more bytes in flight per barrier for the narrow head problem (SS = 4).
   constexpr int MT = 16 * MI, NT = 64 * NI;
+  constexpr int NR = KS + SY - 1;              // staged x rows per channel
   constexpr int SEG = 32 * SS;
   constexpr int RW = SEG + KS - 1;
   constexpr int PWS = [] {  // x row stride (words): >= RW and == KS (mod 32)
@@ -363,15 +365,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     while (v % 32 != KS % 32) ++v;
     return v;
   }();
-  constexpr int PSX = KS * PWS;
+  constexpr int PSX = [] {  // plane (channel) stride in words: >= NR rows and == KS*KS (mod 32), so that bank(n) = n mod 32
+    int v = NR * PWS;
+    while (v % 32 != KK % 32) ++v;
+    return v;
+  }();
   constexpr int CIT = (NT + KK - 2) / KK + 1;
-  constexpr int DZ_U4 = SS * 2 * 4 * MT;       // 16-byte units: [k-step][plane][kq][MT]
+  constexpr int NSUB = SS * SY;                // k-steps per segment; sub = sy*SS + sx
+  constexpr int DZ_U4 = NSUB * 2 * 4 * MT;     // 16-byte units: [k-step][plane][kq][MT]
   constexpr int X_WORDS = CIT * PSX;
   constexpr int BUF_BYTES = DZ_U4 * 16 + ((X_WORDS * 4 + 15) / 16) * 16;
-  constexpr int DITEMS = SS * 4 * MT;          // (co, pixel octet) staging items
+  constexpr int DITEMS = NSUB * 4 * MT;        // (co, row, pixel octet) staging items
   constexpr int DPT = (DITEMS + 255) / 256;
   constexpr int Q = (RW + 3) / 4;
-  constexpr int XF = CIT * KS * Q;
+  constexpr int XF = CIT * NR * Q;
   constexpr int XPT4 = (XF + 255) / 256;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -405,17 +412,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < DPT; ++i) {
       const int e = ptid + i * 256;
-      const int co = e / (4 * SS);
-      dq8[i] = (e % (4 * SS)) * 8;
+      const int co = e / (4 * NSUB), r2 = e % (4 * NSUB);
+      const int sy = r2 / (4 * SS);
+      dq8[i] = (r2 % (4 * SS)) * 8;
       dok[i] = (e < DITEMS) && (co0 + co < Cout);
-      doff[i] = (unsigned)(((int64_t)(co0 + co) * HW + dq8[i]) * 4);
+      doff[i] = (unsigned)(((int64_t)(co0 + co) * HW + (int64_t)sy * W + dq8[i]) * 4);
     }
     int xoff[XPT4], xlds[XPT4], xrc[XPT4];
 #pragma unroll
     for (int i = 0; i < XPT4; ++i) {
       const int e = ptid + i * 256;
       const int row = e / Q, q = e - row * Q;
-      const int ci_l = row / KS, r = row - ci_l * KS;
+      const int ci_l = row / NR, r = row - ci_l * NR;
       const bool ok = (e < XF) && (ci0 + ci_l < Cin);
       xoff[i] = ((ci0 + ci_l) * (int)HW + (r - PAD) * W + 4 * q - PAD) * 4;   // bytes, relative to (b, channel 0, y, x0)
       xlds[i] = ok ? ci_l * PSX + r * PWS + 4 * q : -1;
@@ -429,7 +437,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto load_seg = [&](int seg, f32x4 (&dv)[DPT][2], f32x4 (&xv)[XPT4]) {
       const int xs = seg % a.segs_x;
       const int by = seg / a.segs_x;
-      const int y = by % H, b = by / H;
+      const int y = (by % (H / SY)) * SY, b = by / (H / SY);   // first of the segment's SY rows
       const int x0 = xs * SEG;
       const unsigned dy_base = (unsigned)((((int64_t)b * Cout) * HW + (int64_t)y * W + x0) * 4);
       const int x_base = (int)((((int64_t)b * Cin) * HW + (int64_t)y * W + x0) * 4);
@@ -462,7 +470,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           }
       }
       if (x0 < PAD || x0 + SEG + PAD > W) {   // halo columns outside the image (left / right edge segments)
-        const int by = seg / a.segs_x;
+        const int by_ = seg / a.segs_x;
+        const int by = (by_ / (H / SY)) * H + (by_ % (H / SY)) * SY;   // b*H + y of the segment's first row
         if (ci0 == 0 && by <= PAD && x0 == 0) {   // first rows of frame 0: the quad loaded from offset 0 (see load_seg)
           const int x_base = by * W * 4;
 #pragma unroll
@@ -488,7 +497,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int i = 0; i < DPT; ++i) {
         const int e = ptid + i * 256;
         if (e < DITEMS) {
-          const int co = e / (4 * SS), oct = e % (4 * SS), sub = oct >> 2, q = oct & 3;
+          const int co = e / (4 * NSUB), r2 = e % (4 * NSUB);
+          const int oct = r2 % (4 * SS), sub = (r2 / (4 * SS)) * SS + (oct >> 2), q = oct & 3;
           u32x4 hi, lo;
           float s = 0.f;
 #pragma unroll
@@ -563,7 +573,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int i = 0; i < DPT; ++i) {
         const int e = ptid + i * 256;
-        if (e < DITEMS) red[e] = db_part[i];   // red[co*(4*SS) + octet]
+        if (e < DITEMS) red[e] = db_part[i];   // red[co*(4*NSUB) + (row, octet)]
       }
     }
     __syncthreads();
@@ -571,8 +581,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
       float t = 0.f;
 #pragma unroll
-      for (int sub = 0; sub < SS; ++sub) {
-        const float* r4 = red + (4 * SS) * ptid + 4 * sub;
+      for (int sub = 0; sub < NSUB; ++sub) {
+        const float* r4 = red + (4 * NSUB) * ptid + 4 * sub;
         t += (r4[0] + r4[1]) + (r4[2] + r4[3]);
       }
       a.slab_db[(int64_t)split * a.co_pad + co0 + ptid] = t;
@@ -604,9 +614,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const u32x4* __restrict__ dz0 = reinterpret_cast<const u32x4*>(smem + cur * BUF_BYTES) + a_lane;
     const unsigned* __restrict__ xw0 = reinterpret_cast<const unsigned*>(smem + cur * BUF_BYTES + DZ_U4 * 16);
 #pragma unroll
-    for (int sub = 0; sub < SS; ++sub) {
+    for (int sub = 0; sub < NSUB; ++sub) {
       const u32x4* __restrict__ dz = dz0 + sub * 8 * MT;
-      const unsigned* __restrict__ xw = xw0 + 32 * sub;
+      const unsigned* __restrict__ xw = xw0 + (sub / SS) * PWS + 32 * (sub % SS);   // row step sy, column step sx
       bf16x8 ah[MI], al[MI];
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
@@ -666,7 +676,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <int MI, int NI, int SS>
+template <int MI, int NI, int SS, int SY>
 int launch_wgrad3p(const Wgrad3Args& a_in, hipStream_t st) {
   constexpr int MT = 16 * MI, NT = 64 * NI;
   constexpr int CIT = (NT + KK - 2) / KK + 1;
@@ -676,14 +686,20 @@ int launch_wgrad3p(const Wgrad3Args& a_in, hipStream_t st) {
     while (v % 32 != KS % 32) ++v;
     return v;
   }();
-  constexpr int BUF_BYTES = SS * 2 * 4 * MT * 16 + ((CIT * KS * PWSP * 4 + 15) / 16) * 16;
+  constexpr int PSXP = [] {
+    int v = (KS + SY - 1) * PWSP;
+    while (v % 32 != KK % 32) ++v;
+    return v;
+  }();
+  constexpr int BUF_BYTES = SS * SY * 2 * 4 * MT * 16 + ((CIT * PSXP * 4 + 15) / 16) * 16;
   size_t lds = (size_t)2 * BUF_BYTES;
+  if (a_in.H % SY != 0) return NQ_ERR_UNSUPPORTED;
   Wgrad3Args a = a_in;
-  a.segs_x = (a.W + SEGP - 1) / SEGP;       // segments of 32*SS pixels
-  a.nseg = a.segs_x * a.H * a.B;
+  a.segs_x = (a.W + SEGP - 1) / SEGP;       // segments of SY rows x 32*SS pixels
+  a.nseg = a.segs_x * (a.H / SY) * a.B;
   dim3 grid((unsigned)a.nsplit, (unsigned)(a.n_pad / NT), (unsigned)(a.co_pad / MT));
-  if (int rc = nq_lds_optin<&conv_wgrad3p_kernel<MI, NI, SS>>(lds)) return rc;
-  hipLaunchKernelGGL((conv_wgrad3p_kernel<MI, NI, SS>), grid, dim3(512), lds, st, a);
+  if (int rc = nq_lds_optin<&conv_wgrad3p_kernel<MI, NI, SS, SY>>(lds)) return rc;
+  hipLaunchKernelGGL((conv_wgrad3p_kernel<MI, NI, SS, SY>), grid, dim3(512), lds, st, a);
   return nq_launch_status();
 }
 
@@ -722,14 +738,15 @@ extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, 
     a.dbg = e ? atoi(e) : 0;
   }
   if (pc) {   // producer / consumer variant (wide n-tiles only; the plan sized nsplit for one 8-wave workgroup per CU);
-              // pc = number of 32-pixel k-steps per staged segment (1 or 2)
+              // pc: 1 = one row x 32 pixels per segment, 12 / 14 = 2 / 4 rows x 32 pixels, 4 = one row x 128 pixels (head)
 #define NQ_WG3P(MI_, NI_)                                                                   \
-  return pc == 2 ? launch_wgrad3p<MI_, NI_, 2>(a, st) : launch_wgrad3p<MI_, NI_, 1>(a, st);
+  return pc == 14 ? launch_wgrad3p<MI_, NI_, 1, 4>(a, st)                                   \
+                  : (pc == 12 ? launch_wgrad3p<MI_, NI_, 1, 2>(a, st) : launch_wgrad3p<MI_, NI_, 1, 1>(a, st));
     if (ni_sel == 1) {   // narrow problems (the role-swapped head gradient): 128-pixel segments keep enough bytes in flight
       if (pc != 4) return NQ_ERR_UNSUPPORTED;
       switch (mi_sel) {
-        case 2: return launch_wgrad3p<2, 1, 4>(a, st);
-        case 3: return launch_wgrad3p<3, 1, 4>(a, st);
+        case 2: return launch_wgrad3p<2, 1, 4, 1>(a, st);
+        case 3: return launch_wgrad3p<3, 1, 4, 1>(a, st);
         default: return NQ_ERR_UNSUPPORTED;
       }
     }
