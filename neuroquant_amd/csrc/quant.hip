@@ -143,7 +143,10 @@ __device__ __forceinline__ float ada_bwd_elem(float xv, float gyv, float a, floa
     float c = h - 0.5f;
     float t = fabsf(c) * 2.f;
     float sg = (c > 0.f) ? 1.f : ((c < 0.f) ? -1.f : 0.f);
-    float dRdh = -reg_weight * (reg_b * powf(t, reg_b - 1.f)) * 2.f * sg;
+    // t^(b-1), t in [0,1], b-1 >= 1, as exp2((b-1) * log2 t) on the two hardware transcendentals (relative error ~2e-6 at
+    // b = 20; t = 0 -> 2^-inf = 0 like powf): the library powf was half of this kernel's time
+    const float tp = __builtin_amdgcn_exp2f((reg_b - 1.f) * __builtin_amdgcn_logf(t));
+    float dRdh = -reg_weight * (reg_b * tp) * 2.f * sg;
     g += dRdh * hp;
   }
   return g;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/hbm_traffic.json (what bench.py reports as roofline.traffic) from a PMC summary made by summarize.py.
 
-    python3 profiles/make_traffic.py profiles/r02_a_pmc_conv_kernels.json
+    python3 profiles/make_traffic.py profiles/r02_b_pmc_conv_kernels.json
 
 bytes = read + write per launch at per-GPU batch 2: FETCH_SIZE x 2 (gfx950 reports half the bytes of 16-byte-per-lane
 streaming reads, MI355X_MICROARCH.md §HBM; separate --pmc pass) + WRITE_SIZE (its own pass).  FETCH_SIZE counts the L2's
@@ -14,10 +14,10 @@ import sys
 
 # bench key -> (kernel name in the PMC summary, grid size) for HNeRV Bunny_1280x640_3M, B = 2
 MAP = {
-    "conv_wgrad3_k5_44_148": ("conv_wgrad3p_kernel<5, 6>", None),
+    "conv_wgrad3_k5_44_148": ("conv_wgrad3p_kernel<5, 6, 1, 4>", None),
     "conv_igemm3_k5_44_148": ("conv_igemm3_kernel<5>", 819200),
     "conv_igemm3_k5_148_44": ("conv_igemm3_kernel<3>", 409600),
-    "conv_wgrad3_k5_53_176": ("conv_wgrad3p_kernel<4, 7>", None),
+    "conv_wgrad3_k5_53_176": ("conv_wgrad3p_kernel<4, 7, 1, 4>", None),
     "conv_igemm3_k5_53_176": ("conv_igemm3_kernel<4>", 307200),
     "conv_igemm3_k5_176_53": ("conv_igemm3_kernel<4>", 102400),
 }
