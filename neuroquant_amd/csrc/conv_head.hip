@@ -39,8 +39,11 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 
   const int tid = threadIdx.x;
   const int row = tid >> 4, c4 = (tid & 15) * 4;
-  const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
-  const int x0 = tile_x * TW, y0 = tile_y * TH, b = blockIdx.y;
+  // 1-D grid over (image, tile), XCD-chunked (nq_xcd_chunk): neighbouring tiles share halo rows / lines behind one L2
+  const int lid = nq_xcd_chunk((int)blockIdx.x, (int)gridDim.x);
+  const int tiles = tiles_x * ((H + TH - 1) / TH), tile = lid % tiles;
+  const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+  const int x0 = tile_x * TW, y0 = tile_y * TH, b = lid / tiles;
   const int64_t HW = (int64_t)H * W;
   const float* __restrict__ xb = x + (int64_t)b * Cin * HW;
   const bool w4 = (W & 3) == 0;
@@ -156,8 +159,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS <= 3 &&
 
   const int tid = threadIdx.x;
   const int row = tid / TPR, c4 = (tid % TPR) * PX;
-  const int tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
-  const int x0 = tile_x * TW, y0 = tile_y * TH, b = blockIdx.y;
+  // 1-D grid over (image, tile), XCD-chunked (nq_xcd_chunk): neighbouring tiles share halo rows / lines behind one L2
+  const int lid = nq_xcd_chunk((int)blockIdx.x, (int)gridDim.x);
+  const int tiles = tiles_x * ((H + TH - 1) / TH), tile = lid % tiles;
+  const int tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+  const int x0 = tile_x * TW, y0 = tile_y * TH, b = lid / tiles;
   const int64_t HW = (int64_t)H * W;
   const float* __restrict__ dyb = dy + (int64_t)b * CO * HW;
 
@@ -280,7 +286,7 @@ int nq_head_supported(int Cout, int k) { return Cout <= MAXCO && (k == 1 || k ==
 int nq_head_forward(const float* x, const float* wt, int ld, const float* bias, float* y, int B, int Cin, int H, int W,
                     int Cout, int k, int epi, hipStream_t st) {
   const int tiles_x = (W + 63) / 64, tiles = tiles_x * ((H + 15) / 16);
-  dim3 g((unsigned)tiles, (unsigned)B), blk(256);
+  dim3 g((unsigned)(tiles * B)), blk(256);
   switch (k) {
     case 1: hipLaunchKernelGGL(head_fwd_kernel<1>, g, blk, 0, st, x, wt, ld, bias, y, Cin, H, W, Cout, epi, tiles_x); break;
     case 3: hipLaunchKernelGGL(head_fwd_kernel<3>, g, blk, 0, st, x, wt, ld, bias, y, Cin, H, W, Cout, epi, tiles_x); break;
@@ -297,7 +303,7 @@ int nq_head_dgrad(const float* dy, const float* wt, int ld, const float* zprev, 
   const bool px8 = r2 && (W % 8 == 0) && k <= 3;
   const int th = px8 ? 32 : 16;
   const int tiles_x = (W + 63) / 64, tiles = tiles_x * ((H + th - 1) / th);
-  dim3 g((unsigned)tiles, (unsigned)B), blk(256);
+  dim3 g((unsigned)(tiles * B)), blk(256);
 #define NQ_HD(KS_, R2_, PX_)                                                                                          \
   do {                                                                                                                \
     if (Cout <= 3)                                                                                                    \

@@ -45,7 +45,7 @@ struct Conv3Args {
   float* y;
   float* z;
   const float* zprev;
-  int B, Cin, H, W, Cout, r, epi, tiles_x, nchunk, co_tiles;
+  int B, Cin, H, W, Cout, r, epi, tiles_x, tiles, nchunk, co_tiles;
   int nsplit, per_split;  // split-K over channel chunks: blockIdx.z = b*nsplit + split, chunks [split*per, +per)
   float* slab;            // [nsplit][B][Cout][H][W] raw partial sums when nsplit > 1 (nq_conv_splitk_finish adds them)
   int lds_epi;            // the launch reserved MT*1024 B of LDS: the data-gradient epilogue may transpose through it
@@ -103,10 +103,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
-  const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+  // 1-D grid, XCD-chunked: logical id = (z * tiles + tile) * co_tiles + cot -- the co-tiles of one patch and the tiles
+  // next to it (shared halo rows, shared 128-byte lines at the row ends) run together behind one L2
+  const int lid = nq_xcd_chunk((int)blockIdx.x, (int)gridDim.x);
+  const int cot = lid % a.co_tiles, lt = lid / a.co_tiles;
+  const int tile = lt % a.tiles, bz = lt / a.tiles;
+  const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
   const int x0 = tile_x * TW, y0 = tile_y * TH;
-  const int cot = blockIdx.y, co0 = cot * MT;
-  const int b = blockIdx.z / a.nsplit, split = blockIdx.z - b * a.nsplit;
+  const int co0 = cot * MT;
+  const int b = bz / a.nsplit, split = bz - b * a.nsplit;
   const int c_lo = split * a.per_split;  // first chunk of this split
   const int H = a.H, W = a.W, Cin = a.Cin - c_lo * CC;  // channels from this split's first one on
   const int64_t HW = (int64_t)H * W;
@@ -561,8 +566,8 @@ int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
     if (lds < (size_t)MT * 1024) lds = (size_t)MT * 1024;
   }
   if (int rc = nq_lds_optin<&conv_igemm3_kernel<MI>>(lds)) return rc;
-  hipLaunchKernelGGL(conv_igemm3_kernel<MI>, dim3((unsigned)tiles, (unsigned)a.co_tiles, (unsigned)(a.B * a.nsplit)), dim3(256),
-                     lds, st, a);
+  a.tiles = tiles;
+  hipLaunchKernelGGL(conv_igemm3_kernel<MI>, dim3((unsigned)(tiles * a.co_tiles * a.B * a.nsplit)), dim3(256), lds, st, a);
   return nq_launch_status();
 }
 

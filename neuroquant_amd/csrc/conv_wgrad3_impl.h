@@ -95,9 +95,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
-  const int split = blockIdx.x;
-  const int n0 = blockIdx.y * NT;
-  const int co0 = blockIdx.z * MT;
+  // 1-D grid, XCD-chunked (nq_xcd_chunk): logical id = (split * n_tiles + n_tile) * co_tiles + co_tile -- the
+  // workgroups that read the same segments (same x rows for every co tile, same dY rows for every n tile) and the splits
+  // next to them (x halo rows, shared 128-byte lines at the segment ends) run together behind one L2
+  const int lid = nq_xcd_chunk((int)blockIdx.x, (int)gridDim.x);
+  const int co_tiles = a.co_pad / MT, n_tiles = a.n_pad / NT;
+  const int split = lid / (co_tiles * n_tiles);
+  const int n_tile = (lid / co_tiles) % n_tiles;
+  const int n0 = n_tile * NT;
+  const int co0 = (lid % co_tiles) * MT;
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, N = a.N;
   const int ci0 = n0 / KK;
   const int64_t HW = (int64_t)H * W;
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   float db_part[DPT];
 #pragma unroll
   for (int i = 0; i < DPT; ++i) db_part[i] = 0.f;
-  const bool do_db = (blockIdx.y == 0) && a.slab_db != nullptr;
+  const bool do_db = (n_tile == 0) && a.slab_db != nullptr;
 
   const int seg_lo = (int)(((int64_t)a.nseg * split) / a.nsplit);
   const int seg_hi = (int)(((int64_t)a.nseg * (split + 1)) / a.nsplit);
@@ -385,9 +391,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int split = blockIdx.x;
-  const int n0 = blockIdx.y * NT;
-  const int co0 = blockIdx.z * MT;
+  // 1-D grid, XCD-chunked (nq_xcd_chunk): logical id = (split * n_tiles + n_tile) * co_tiles + co_tile -- the
+  // workgroups that read the same segments (same x rows for every co tile, same dY rows for every n tile) and the splits
+  // next to them (x halo rows, shared 128-byte lines at the segment ends) run together behind one L2
+  const int lid = nq_xcd_chunk((int)blockIdx.x, (int)gridDim.x);
+  const int co_tiles = a.co_pad / MT, n_tiles = a.n_pad / NT;
+  const int split = lid / (co_tiles * n_tiles);
+  const int n_tile = (lid / co_tiles) % n_tiles;
+  const int n0 = n_tile * NT;
+  const int co0 = (lid % co_tiles) * MT;
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, N = a.N;
   const int ci0 = n0 / KK;
   const int64_t HW = (int64_t)H * W;
@@ -432,7 +444,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float db_part[DPT];
 #pragma unroll
     for (int i = 0; i < DPT; ++i) db_part[i] = 0.f;
-    const bool do_db = (blockIdx.y == 0) && a.slab_db != nullptr;
+    const bool do_db = (n_tile == 0) && a.slab_db != nullptr;
 
     auto load_seg = [&](int seg, f32x4 (&dv)[DPT][2], f32x4 (&xv)[XPT4]) {
       const int xs = seg % a.segs_x;
@@ -697,7 +709,7 @@ int launch_wgrad3p(const Wgrad3Args& a_in, hipStream_t st) {
   Wgrad3Args a = a_in;
   a.segs_x = (a.W + SEGP - 1) / SEGP;       // segments of SY rows x 32*SS pixels
   a.nseg = a.segs_x * (a.H / SY) * a.B;
-  dim3 grid((unsigned)a.nsplit, (unsigned)(a.n_pad / NT), (unsigned)(a.co_pad / MT));
+  dim3 grid((unsigned)(a.nsplit * (a.n_pad / NT) * (a.co_pad / MT)));
   if (int rc = nq_lds_optin<&conv_wgrad3p_kernel<MI, NI, SS, SY>>(lds)) return rc;
   hipLaunchKernelGGL((conv_wgrad3p_kernel<MI, NI, SS, SY>), grid, dim3(512), lds, st, a);
   return nq_launch_status();
@@ -710,7 +722,7 @@ int launch_wgrad3(const Wgrad3Args& a, hipStream_t st) {
   constexpr int CIT = (NT + KK - 2) / KK + 1;
   constexpr int BUF_BYTES = 2 * 4 * MT * 16 + ((CIT * PSX * 4 + 15) / 16) * 16;
   size_t lds = (size_t)2 * BUF_BYTES;
-  dim3 grid((unsigned)a.nsplit, (unsigned)(a.n_pad / NT), (unsigned)(a.co_pad / MT));
+  dim3 grid((unsigned)(a.nsplit * (a.n_pad / NT) * (a.co_pad / MT)));
   if (int rc = nq_lds_optin<&conv_wgrad3_kernel<MI, NI>>(lds)) return rc;
   hipLaunchKernelGGL((conv_wgrad3_kernel<MI, NI>), grid, dim3(256), lds, st, a);
   return nq_launch_status();

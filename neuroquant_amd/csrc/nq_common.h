@@ -35,6 +35,17 @@ static inline int nq_lds_optin(size_t lds) {
   return NQ_OK;
 }
 
+// XCD-aware workgroup order.  The dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs, each with its
+// own 4 MiB L2 (MI355X_MICROARCH.md, L2): with the plain id -> tile map, tiles that share halo rows / cache lines /
+// an operand panel never meet in one L2 and every shared line is fetched once per XCD.  This bijection hands XCD k (the
+// ids with id % 8 == k, in dispatch order) a CONTIGUOUS range of logical ids, so neighbouring tiles run at the same
+// time behind the same L2.  Speed and HBM traffic only -- never correctness.
+__device__ __forceinline__ int nq_xcd_chunk(int id, int n) {
+  const int q = n >> 3, r = n & 7;          // XCD k owns q + (k < r) ids
+  const int k = id & 7, i = id >> 3;
+  return k * q + (k < r ? k : r) + i;
+}
+
 // exact-erf GELU and its derivative (nn.GELU(), reference models/_layers.py:104-105) from ONE exponential: the
 // Gaussian exp(-v^2/2) that gelu' needs is also the exponential of erf(v/sqrt 2) = 1 - P(t) exp(-v^2/2), t = 1/(1 + p|v|/sqrt 2)
 // (Abramowitz & Stegun 7.1.26, |error| <= 1.5e-7 -- at the rounding level of an fp32 erf; measured against float64 over
