@@ -37,7 +37,7 @@ struct ConvArgs {
   const float* bias;
   float* y;
   float* z;
-  int B, Cin, H, W, Cout, ld, r, epi, tiles_x, ncg, nsplit, in_gelu;
+  int B, Cin, H, W, Cout, ld, r, epi, tiles_x, tiles, co_tiles, ncg, nsplit, in_gelu;
   const float* zprev;  // NQ_EPI_DGRAD_GELU: pre-activation of the layer below, (B,Cout,H,W)
   float* slab;  // [nsplit][B][Cout][H][W] partial sums when nsplit > 1
 };
@@ -96,10 +96,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
-  const int tile_x = blockIdx.x % a.tiles_x, tile_y = blockIdx.x / a.tiles_x;
+  // 1-D grid, XCD-chunked (nq_xcd_chunk): logical id = (z * tiles + tile) * co_tiles + co_tile
+  const int lid = nq_xcd_chunk((int)blockIdx.x, (int)gridDim.x);
+  const int lt = lid / a.co_tiles, tile = lt % a.tiles, bz = lt / a.tiles;
+  const int tile_x = tile % a.tiles_x, tile_y = tile / a.tiles_x;
   const int x0 = tile_x * TW, y0 = tile_y * TH;
-  const int co0 = blockIdx.y * MT;
-  const int b = blockIdx.z / a.nsplit, split = blockIdx.z - b * a.nsplit;
+  const int co0 = (lid % a.co_tiles) * MT;
+  const int b = bz / a.nsplit, split = bz - b * a.nsplit;
   const int H = a.H, W = a.W, Cin = a.Cin;
   const float* __restrict__ xb = a.x + (int64_t)b * Cin * H * W;
   const float* __restrict__ wt = a.wt + co0;
@@ -446,7 +449,9 @@ extern "C" int nq_conv_splitk_finish(const float* slab, const float* bias, float
 #endif
 
 template <int MI>
-int launch_igemm(const ConvArgs& a, int tiles, int co_tiles, hipStream_t st) {
+int launch_igemm(const ConvArgs& a_in, int tiles, int co_tiles, hipStream_t st) {
+  ConvArgs a = a_in;
+  a.tiles = tiles; a.co_tiles = co_tiles;
   constexpr int MT = 16 * MI;
   constexpr int LDW = [] {
     int v = MT;
@@ -455,8 +460,7 @@ int launch_igemm(const ConvArgs& a, int tiles, int co_tiles, hipStream_t st) {
   }();
   size_t lds = (size_t)(2 * PATCH_FLOATS + 2 * WROWS1 * khs_for(MI) * LDW) * sizeof(float);
   if (int rc = nq_lds_optin<&conv_igemm_kernel<MI>>(lds)) return rc;
-  hipLaunchKernelGGL(conv_igemm_kernel<MI>, dim3((unsigned)tiles, (unsigned)co_tiles, (unsigned)(a.B * a.nsplit)), dim3(256), lds, st,
-                     a);
+  hipLaunchKernelGGL(conv_igemm_kernel<MI>, dim3((unsigned)(tiles * co_tiles * a.B * a.nsplit)), dim3(256), lds, st, a);
   return nq_launch_status();
 }
 

@@ -67,9 +67,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
-  const int split = blockIdx.x;
-  const int n0 = blockIdx.y * NT;
-  const int co0 = blockIdx.z * MT;
+  // 1-D grid, XCD-chunked (nq_xcd_chunk): logical id = (split * n_tiles + n_tile) * co_tiles + co_tile
+  const int lid = nq_xcd_chunk((int)blockIdx.x, (int)gridDim.x);
+  const int co_tiles = a.co_pad / MT, n_tiles = a.n_pad / NT;
+  const int split = lid / (co_tiles * n_tiles);
+  const int n_tile = (lid / co_tiles) % n_tiles;
+  const int n0 = n_tile * NT;
+  const int co0 = (lid % co_tiles) * MT;
   const int H = a.H, W = a.W, Cin = a.Cin, Cout = a.Cout, N = a.N;
   const int ci0 = n0 / KK;
   const int64_t HW = (int64_t)H * W;
@@ -92,7 +96,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
   float db_acc = 0.f;
-  const bool do_db = (blockIdx.y == 0) && a.slab_db != nullptr;
+  const bool do_db = (n_tile == 0) && a.slab_db != nullptr;
 
   const int seg_lo = (int)(((int64_t)a.nseg * split) / a.nsplit);
   const int seg_hi = (int)(((int64_t)a.nseg * (split + 1)) / a.nsplit);
@@ -264,7 +268,7 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   constexpr int MT = 16 * MI, NT = 64 * NI;
   constexpr int CIT = (NT + KK - 2) / KK + 1;
   size_t lds = (size_t)2 * (MT * LDP + CIT * PSX) * sizeof(float);
-  dim3 grid((unsigned)a.nsplit, (unsigned)(a.n_pad / NT), (unsigned)(a.co_pad / MT));
+  dim3 grid((unsigned)(a.nsplit * (a.n_pad / NT) * (a.co_pad / MT)));
   if (int rc = nq_lds_optin<&conv_wgrad_kernel<MI, NI>>(lds)) return rc;
   hipLaunchKernelGGL((conv_wgrad_kernel<MI, NI>), grid, dim3(256), lds, st, a);
   return nq_launch_status();
