@@ -344,6 +344,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// dY staging item e of the producer/consumer kernel -> (channel, k-step, pixel octet); see the image comment in the kernel
+struct DItem { int co, sub, q; };
+template <int NSUB>
+__device__ __forceinline__ DItem ditem(int e) {
+  constexpr int G = 4 / NSUB;
+  const int qlo = e & 1;
+  int t = e >> 1;
+  const int sub = t % NSUB;
+  t /= NSUB;
+  const int co_lo = t % G;
+  t /= G;
+  const int qhi = t & 1;
+  return DItem{(t >> 1) * G + co_lo, sub, 2 * qhi + qlo};
+}
+
 constexpr int ni3_for(int mi) { return mi <= 3 ? 6 : (mi <= 4 ? 6 : 6); }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -378,7 +393,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }();
   constexpr int CIT = (NT + KK - 2) / KK + 1;
   constexpr int NSUB = SS * SY;                // k-steps per segment; sub = sy*SS + sx
-  constexpr int DZ_U4 = NSUB * 2 * 4 * MT;     // 16-byte units: [k-step][plane][kq][MT]
+  // dY image, 16-byte units: [k-step: SUBS][plane: 4*MT][kq: MT][co ^ (kq >= 2 ? 4 : 0)].  The A-fragment reads
+  // (ds_read_b128, served in 16-lane groups that pair kq 0|1 and 2|3) need the kq stride == 0 (mod 16 units); the
+  // producers' ds_write_b128 is served in groups of 8 CONTIGUOUS lanes with bank = unit mod 8, so the 8 items of a group
+  // must land on 8 different units mod 8 -- with the plain [k-step][plane][kq][co] image and items ordered (co, row,
+  // octet) the 8 lanes of a group held ONE channel: an 8-way conflict, 64 LDS cycles per store instead of 8 (dec5:
+  // 10 stores per producer thread and segment).  Here the item order is (co_hi, q_hi, co_lo, k-step, q_lo) (fastest
+  // last), the k-step stride is == G (mod 8) and channels of lane groups kq >= 2 are XOR-ed with 4: a group's 8 items
+  // {G channels} x {NSUB k-steps} x {octets q, q+1 -> kq = (0,2) or (1,3)} cover all 8 residues.
+  static_assert(NSUB == 1 || NSUB == 2 || NSUB == 4, "item order below assumes 1, 2 or 4 k-steps per segment");
+  constexpr int G = 4 / NSUB;                  // channels per 8-lane store group
+  constexpr int SUBS = 8 * MT + G;             // k-step stride
+  constexpr int DZ_U4 = NSUB * SUBS;
   constexpr int X_WORDS = CIT * PSX;
   constexpr int BUF_BYTES = DZ_U4 * 16 + ((X_WORDS * 4 + 15) / 16) * 16;
   constexpr int DITEMS = NSUB * 4 * MT;        // (co, row, pixel octet) staging items
@@ -424,11 +450,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < DPT; ++i) {
       const int e = ptid + i * 256;
-      const int co = e / (4 * NSUB), r2 = e % (4 * NSUB);
-      const int sy = r2 / (4 * SS);
-      dq8[i] = (r2 % (4 * SS)) * 8;
-      dok[i] = (e < DITEMS) && (co0 + co < Cout);
-      doff[i] = (unsigned)(((int64_t)(co0 + co) * HW + (int64_t)sy * W + dq8[i]) * 4);
+      const DItem it = ditem<NSUB>(e);
+      const int sy = it.sub / SS, sx = it.sub % SS;
+      dq8[i] = (sx * 4 + it.q) * 8;
+      dok[i] = (e < DITEMS) && (co0 + it.co < Cout);
+      doff[i] = (unsigned)(((int64_t)(co0 + it.co) * HW + (int64_t)sy * W + dq8[i]) * 4);
     }
     int xoff[XPT4], xlds[XPT4], xrc[XPT4];
 #pragma unroll
@@ -509,8 +535,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int i = 0; i < DPT; ++i) {
         const int e = ptid + i * 256;
         if (e < DITEMS) {
-          const int co = e / (4 * NSUB), r2 = e % (4 * NSUB);
-          const int oct = r2 % (4 * SS), sub = (r2 / (4 * SS)) * SS + (oct >> 2), q = oct & 3;
+          const DItem it = ditem<NSUB>(e);
+          const int kqd = oct_of(it.q);             // pixel octet q of a k-step is held by lane group oct_of(q)
+          u32x4* const dst = dz + it.sub * SUBS + kqd * MT + (it.co ^ ((kqd & 2) << 1));
           u32x4 hi, lo;
           float s = 0.f;
 #pragma unroll
@@ -523,8 +550,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             lo[j] = pk_bf16(f0 - lo_as_f32(h2), f1 - hi_as_f32(h2));
           }
           db_part[i] += s;
-          dz[sub * 8 * MT + oct_of(q) * MT + co] = hi;       // pixel octet q of k-step sub is held by lane group oct_of(q)
-          dz[sub * 8 * MT + 4 * MT + oct_of(q) * MT + co] = lo;
+          dst[0] = hi;
+          dst[4 * MT] = lo;
         }
       }
 #pragma unroll
@@ -585,7 +612,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int i = 0; i < DPT; ++i) {
         const int e = ptid + i * 256;
-        if (e < DITEMS) red[e] = db_part[i];   // red[co*(4*NSUB) + (row, octet)]
+        const DItem it = ditem<NSUB>(e);
+        if (e < DITEMS) red[it.co * (4 * NSUB) + it.sub * 4 + it.q] = db_part[i];   // red[co][k-step][octet]
       }
     }
     __syncthreads();
@@ -613,7 +641,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int kh = rem / KS, kw = rem - kh * KS;
     lc[ni] = (ci - ci0) * PSX + kh * PWS + kw + 8 * oct_of(kq);
   }
-  const int a_lane = kq * MT + l16;
+  const int a_lane = kq * MT + (l16 ^ ((kq & 2) << 1));   // the producers' image: channels of kq >= 2 are XOR-ed with 4
   f32x4 acc[MI][NI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -627,7 +655,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const unsigned* __restrict__ xw0 = reinterpret_cast<const unsigned*>(smem + cur * BUF_BYTES + DZ_U4 * 16);
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
-      const u32x4* __restrict__ dz = dz0 + sub * 8 * MT;
+      const u32x4* __restrict__ dz = dz0 + sub * SUBS;
       const unsigned* __restrict__ xw = xw0 + (sub / SS) * PWS + 32 * (sub % SS);   // row step sy, column step sx
       bf16x8 ah[MI], al[MI];
 #pragma unroll
@@ -703,7 +731,7 @@ int launch_wgrad3p(const Wgrad3Args& a_in, hipStream_t st) {
     while (v % 32 != KK % 32) ++v;
     return v;
   }();
-  constexpr int BUF_BYTES = SS * SY * 2 * 4 * MT * 16 + ((CIT * PSXP * 4 + 15) / 16) * 16;
+  constexpr int BUF_BYTES = SS * SY * (8 * MT + 4 / (SS * SY)) * 16 + ((CIT * PSXP * 4 + 15) / 16) * 16;   // as in the kernel
   size_t lds = (size_t)2 * BUF_BYTES;
   if (a_in.H % SY != 0) return NQ_ERR_UNSUPPORTED;
   Wgrad3Args a = a_in;
