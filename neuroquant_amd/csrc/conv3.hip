@@ -267,6 +267,9 @@ int nq_conv3_supported(int B, int Cin, int H, int W, int Cout, int k) {
   // <= 4 channels on either side (the image head): the streaming VALU kernels of conv_head.hip are faster than a
   // >80 %-padded MFMA tile (measured 0.17 / 0.23 ms vs 0.21 / 0.38 ms, forward / data gradient of 37->3 at 640x1280)
   if (!(k == 3 || k == 5) || B <= 0 || Cin <= 0 || Cout <= 4 || Cin <= 4) return 0;
+  // the kernel addresses the input with 32-bit buffer offsets (conv_igemm3_impl.h): tensors of 4 GiB and more stay on
+  // the fp32 kernels
+  if ((int64_t)B * Cin * H * W * 4 >= 0xFFFFFF00ll) return 0;
   const Fwd3Plan p = plan_fwd3(B, Cin, H, W, Cout);
   return p.wgs * p.nsplit >= 192;  // still smaller grids stay on the fp32 split-K kernel
 }

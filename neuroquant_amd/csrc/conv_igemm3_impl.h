@@ -49,10 +49,17 @@ struct Conv3Args {
   int nsplit, per_split;  // split-K over channel chunks: blockIdx.z = b*nsplit + split, chunks [split*per, +per)
   float* slab;            // [nsplit][B][Cout][H][W] raw partial sums when nsplit > 1 (nq_conv_splitk_finish adds them)
   int lds_epi;            // the launch reserved MT*1024 B of LDS: the data-gradient epilogue may transpose through it
+  unsigned w_bytes;       // size of the wt3 operand (buffer resource range)
   int tail8;              // the LAST channel chunk holds <= 8 channels: it runs NST8 k-steps of (1 octet x 4 taps) instead of
                           // NST steps of (2 octets x 2 taps) -- 7 instead of 13 steps for k = 5 (no MFMAs on an all-zero octet)
 };
 
+// Timing experiments only (never in the product build): -DNQ_IG3_ABL=n compiles the kernel WITHOUT one of its parts
+// (results are wrong): 1 patch global loads, 2 patch conversion + LDS stores, 3 the MFMAs, 4 the epilogue's global
+// traffic, 5 weight global loads + LDS stores, 6 the B-fragment LDS reads (tools/ablate_igemm3.sh).
+#ifndef NQ_IG3_ABL
+#define NQ_IG3_ABL 0
+#endif
 constexpr int KS = NQ_KS;
 constexpr int KK = KS * KS;
 constexpr int PAD = KS / 2;
@@ -119,7 +126,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // weights of (chunk c, step s): base + ((c*NST + s) * co_tiles*2 ... see nq_weight_layout3: [c][s][plane][tile][kq][MT]
   const int64_t w_plane_stride = (int64_t)a.co_tiles * 4 * MT;   // in 16-byte units
   const int64_t w_step_stride = 2 * w_plane_stride;
-  const u32x4* __restrict__ wg = reinterpret_cast<const u32x4*>(a.wt3) + (int64_t)c_lo * NST * w_step_stride;
 
   // ---- staging state: weights are prefetched TWO k-steps ahead (two register sets; an L2 round trip under load is
   //      ~2-3 k-steps of MFMA time), the next chunk's patch three steps before it is needed ----
@@ -131,31 +137,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int it_oct = tid / (PH * QP), it_rem = tid - it_oct * (PH * QP);
   const int it_r = it_rem / QP, it_q = it_rem - it_r * QP;
   const int it_gy = y0 - PAD + it_r, it_gx = x0 - PAD + 4 * it_q;
-  const bool it_row = (tid < 2 * PH * QP) && it_gy >= 0 && it_gy < H;
-  const bool it_in = it_gx >= 0 && it_gx + 3 < W;                 // the whole quad is inside the image
-  const int64_t it_off = (int64_t)it_gy * W + it_gx;
+  const bool it_act = tid < 2 * PH * QP;
+  const bool it_row = it_act && it_gy >= 0 && it_gy < H;
+  // Every global load of the K loop is UNCONDITIONAL and branch-free: the compiler can then wait for the oldest register
+  // set with a counted s_waitcnt vmcnt(N) while the younger sets stay in flight.  (With a branch around any load it falls
+  // back to vmcnt(0): publishing the weights of step g+1 then also waited for the loads of step g+2 issued half a step
+  // earlier -- a full L2 round trip exposed per k-step.  Ablation: without the patch loads OR without the weight loads the
+  // dec5 data gradient ran 23 % faster.)  Patch quads are bounds-checked BUFFER loads at 32-bit byte offsets: a row
+  // outside the image or a channel >= Cin gets an out-of-range offset and reads as zero; the partial quads at the left /
+  // right image edge are masked when the values are converted (NQ3_STORE_PATCH), under a block-uniform branch.
+  constexpr unsigned OOB = 0xFFFFFF00u;      // >= num_records (checked by the host: the activation tensor is < 4 GiB)
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.x), 0, (int)(unsigned)((int64_t)a.B * a.Cin * HW * 4), 0x00020000);
+  // byte offset of (this split's channel it_oct*8, row, quad); negative only for the quad that starts in the left halo
+  // of the very first row of the tensor: that one is loaded from offset 0 and shifted into place (prologue)
+  const int it_base = (int)((((int64_t)b * a.Cin + (int64_t)c_lo * CC + it_oct * 8) * HW + (int64_t)it_gy * W + it_gx) * 4);
+  const unsigned HWb = (unsigned)(HW * 4);
+  const bool it_neg = it_row && it_base < 0;
+  const bool x_edge = (x0 == 0) || (x0 + TW + PAD > W);   // block-uniform: some halo columns are outside the image
   f32x4 pv[8];
   u32x4 wvA[WPT], wvB[WPT];
 #define NQ3_LOAD_PATCH(CH)                                                                            \
   {                                                                                                   \
-    const int ch0_ = (CH) * CC + it_oct * 8;                                                          \
-    const float* p_ = xb + (int64_t)ch0_ * HW + it_off;                                               \
+    /* channels of this item's octet that exist (0 for a thread without an item / a row outside the image): the   \
+       offsets are selected with bit masks, not with ?: -- a conditional here comes back as a branch around the load */ \
+    const int nv_ = (NQ_IG3_ABL != 1 && it_row) ? min(max(Cin - ((CH) * CC + it_oct * 8), 0), 8) : 0;  \
+    const unsigned first_ = ((CH) == 0 && it_neg) ? 0u : 0xFFFFFFFFu;                                 \
     _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
-      f32x4 v_ = f32x4{0.f, 0.f, 0.f, 0.f};                                                           \
-      if (it_row && ch0_ + j < Cin) {                                                                 \
-        const float* q_ = p_ + (int64_t)j * HW;                                                       \
-        if (it_in) {                                                                                  \
-          v_ = *reinterpret_cast<const f32x4_u*>(q_);                                                 \
-        } else {                                                                                      \
-          _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                            \
-              if (it_gx + e_ >= 0 && it_gx + e_ < W) v_[e_] = q_[e_];                                 \
-        }                                                                                             \
-      }                                                                                               \
-      pv[j] = v_;                                                                                     \
+      unsigned o_ = (unsigned)it_base + (unsigned)((CH) * CC + j) * HWb;                              \
+      if (j == 0) o_ &= first_;                                                                       \
+      const unsigned sel_ = (unsigned)((j - nv_) >> 31);   /* all ones when j < nv_ */                  \
+      const unsigned off_ = (o_ & sel_) | (OOB & ~sel_);                                              \
+      pv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off_, 0, 0));     \
     }                                                                                                 \
   }
 #define NQ3_STORE_PATCH(DST)                                                                          \
-  if (tid < 2 * PH * QP) {                                                                            \
+  if (NQ_IG3_ABL != 2 && it_act) {                                                                    \
+    if (x_edge) {                                                                                     \
+      _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                                \
+        if (it_gx + e_ < 0 || it_gx + e_ >= W) {                                                      \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) pv[j][e_] = 0.f;                              \
+        }                                                                                             \
+    }                                                                                                 \
     _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) {                                                \
       if (4 * QP == PW || 4 * it_q + e_ < PW) {                                                       \
         const float c_[8] = {pv[0][e_], pv[1][e_], pv[2][e_], pv[3][e_], pv[4][e_], pv[5][e_], pv[6][e_], pv[7][e_]}; \
@@ -169,19 +192,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // weights of global step G (= chunk*NST + step): [G][plane][tile][kq][MT]
 #define NQ3_LOAD_W(SET, G)                                                                            \
   {                                                                                                   \
-    const u32x4* __restrict__ src_ = wg + (int64_t)(G) * w_step_stride + (int64_t)cot * 4 * MT;       \
-    _Pragma("unroll") for (int i = 0; i < WPT; ++i) {                                                 \
-      const int f_ = tid + i * 256;                                                                   \
-      if (i + 1 < WPT || f_ < W_U4) {                                                                 \
-        const int pl_ = f_ / (4 * MT), rem_ = f_ - pl_ * (4 * MT);                                    \
-        SET[i] = src_[pl_ * w_plane_stride + rem_];                                                   \
-      }                                                                                               \
-    }                                                                                                 \
+    /* uniform byte offset of the k-step (past the end: the last step again, never stored) + fixed per-thread offsets */ \
+    const unsigned so_ = (unsigned)(c_lo * NST + min((int)(G), Gm1)) * w_step_bytes;                  \
+    _Pragma("unroll") for (int i = 0; i < WPT; ++i)                                                   \
+      SET[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, wvo[i], so_, 0)); \
   }
 #define NQ3_STORE_W(SET, DST)                                                                         \
   _Pragma("unroll") for (int i = 0; i < WPT; ++i) {                                                   \
     const int f_ = tid + i * 256;                                                                     \
-    if (i + 1 < WPT || f_ < W_U4) (DST)[f_] = SET[i];                                                 \
+    if (NQ_IG3_ABL != 5 && (i + 1 < WPT || f_ < W_U4)) (DST)[f_] = SET[i];                            \
   }
 
   f32x4 acc[MI][4];
@@ -202,10 +221,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const bool tail = a.tail8 && (c_lo + nchunk == a.nchunk);   // this split ends with the short tail chunk
   const int nfull = nchunk - (tail ? 1 : 0);
   const int G = nfull * NST + (tail ? NST8 : 0);
+  const int Gm1 = G - 1;
+  // per-thread byte offsets of its weight units within one k-step (fixed): unit f = tid + i*256 of [plane][kq][MT]; a
+  // thread without an item in the last round loads unit 0 (valid memory, never stored)
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt3), 0, (int)a.w_bytes, 0x00020000);
+  const unsigned w_step_bytes = (unsigned)(w_step_stride * 16);
+  unsigned wvo[WPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int f_ = tid + i * 256;
+    const bool ok_ = NQ_IG3_ABL != 5 && (i + 1 < WPT || f_ < W_U4);
+    const int pl_ = f_ / (4 * MT), rem_ = f_ - pl_ * (4 * MT);
+    wvo[i] = (unsigned)(cot * 4 * MT + (ok_ ? pl_ * (int)w_plane_stride + rem_ : 0)) * 16u;
+  }
   NQ3_LOAD_PATCH(0)
   NQ3_LOAD_W(wvA, 0)
-  if (G > 1) {
-    NQ3_LOAD_W(wvB, 1)
+  NQ3_LOAD_W(wvB, 1)
+  if (it_neg) {   // first row of the tensor, left halo: the quad was loaded from offset 0 (see it_base)
+    const f32x4 v_ = pv[0];
+    if constexpr (PAD == 2) pv[0] = f32x4{0.f, 0.f, v_[0], v_[1]};
+    else if constexpr (PAD == 1) pv[0] = f32x4{0.f, v_[0], v_[1], v_[2]};
   }
   NQ3_STORE_PATCH(patch0)
   NQ3_STORE_W(wvA, wl0)
@@ -213,12 +248,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (G > 1) {
       NQ3_STORE_W(wvB, wl0 + W_U4)
     }
-    if (G > 2) {
-      NQ3_LOAD_W(wvA, 2)
-    }
-    if (G > 3) {
-      NQ3_LOAD_W(wvB, 3)
-    }
+    NQ3_LOAD_W(wvA, 2)
+    NQ3_LOAD_W(wvB, 3)
   }
   __syncthreads();
 
@@ -240,20 +271,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr int gp = (PAR + st) & 1;  // parity of the global step
       const int g = g0 + st;
       if constexpr (!R4) {
-        if (g + 2 < G) {
-          if constexpr (gp == 0) {
-            NQ3_LOAD_W(wvA, g + 2)
-          } else {
-            NQ3_LOAD_W(wvB, g + 2)
-          }
+        if constexpr (gp == 0) {
+          NQ3_LOAD_W(wvA, g + 2)
+        } else {
+          NQ3_LOAD_W(wvB, g + 2)
         }
       }
       if constexpr (!TAIL) {
         constexpr int pst = (NST >= 3) ? NST - 3 : 0;
-        if constexpr (st == pst) {
-          if (ch + 1 < nchunk) {
-            NQ3_LOAD_PATCH(ch + 1)
-          }
+        if constexpr (st == pst) {   // past the last chunk of the tensor the channels are >= Cin: nothing is fetched
+          NQ3_LOAD_PATCH(ch + 1)
         }
       }
       const u32x4* __restrict__ pbt;
@@ -276,7 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       bf16x8 bh[4], bl[4];
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
-        const int o = (nb >> 1) * PW + (nb & 1) * 16;
+        const int o = (NQ_IG3_ABL == 6) ? 0 : (nb >> 1) * PW + (nb & 1) * 16;   // ablation 6: one fragment pair for all four
         bh[nb] = __builtin_bit_cast(bf16x8, pbt[o]);
         bl[nb] = __builtin_bit_cast(bf16x8, pbt[2 * PP + o]);
       }
@@ -290,12 +317,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         // product-major order: the three MFMAs that accumulate into one register are 4 issues apart (a dependent MFMA
         // issued back to back waits for its predecessor's result: the compiler otherwise chains them through a temporary)
+        if constexpr (NQ_IG3_ABL == 3) {   // keep the fragment reads alive without the matrix pipe
+#pragma unroll
+          for (int nb = 0; nb < 4; ++nb) {
+            const u32x4 t0 = __builtin_bit_cast(u32x4, ah), t1 = __builtin_bit_cast(u32x4, bh[nb]), t2 = __builtin_bit_cast(u32x4, bl[nb]),
+                        t3 = __builtin_bit_cast(u32x4, al);
+            acc[mi][nb][0] += __builtin_bit_cast(float, t0[0] ^ t1[0] ^ t2[0] ^ t3[0]);
+          }
+        } else {
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[nb], acc[mi][nb], 0, 0, 0);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[nb], acc[mi][nb], 0, 0, 0);
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) acc[mi][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[nb], acc[mi][nb], 0, 0, 0);
+        }
         if constexpr (mi == (MI - 1) / 2) {
           // publish the next weights in the MIDDLE of the MFMA block (the LDS write latency is covered by the remaining
           // MFMAs instead of sitting in front of the barrier)
@@ -308,12 +344,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 NQ3_STORE_W(wvB, wdst)
               }
             }
-            if (g + 4 < G) {
-              if constexpr (gp == 0) {
-                NQ3_LOAD_W(wvA, g + 4)
-              } else {
-                NQ3_LOAD_W(wvB, g + 4)
-              }
+            if constexpr (gp == 0) {
+              NQ3_LOAD_W(wvA, g + 4)
+            } else {
+              NQ3_LOAD_W(wvB, g + 4)
             }
           } else {              // step g+1 (loaded one step ago) from set (g+1) & 1
             if (g + 1 < G) {
@@ -353,6 +387,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef NQ3_STORE_W
 
   // ---- epilogue (same element mapping as conv_igemm_impl.h; nb = (row 2w + nb/2, column half nb%2)) ----
+  if constexpr (NQ_IG3_ABL == 4) {   // no epilogue traffic: one conditional store keeps the accumulators alive
+    float t = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) t += (acc[mi][nb][0] + acc[mi][nb][1]) + (acc[mi][nb][2] + acc[mi][nb][3]);
+    if (t == 1.2345e-30f) a.y[tid] = t;
+    return;
+  }
   const int Cout = a.Cout, r = a.r, rr = a.r * a.r;
   const int cob = co0 + 4 * kq;
   if (a.nsplit > 1) {  // raw partial sums of this split; bias / activation happen in the finish kernel
@@ -579,6 +622,7 @@ int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
 extern "C" int NQ_CAT(nq_conv_igemm3_k, NQ_KS)(const float* x, const void* wt3, const float* bias, float* y, float* z,
                                                 const float* zprev, int B, int Cin, int H, int W, int Cout, int r, int epi,
                                                 int mi_sel, int nsplit, int per_split, float* slab, hipStream_t st) {
+  if ((int64_t)B * Cin * H * W * 4 >= 0xFFFFFF00ll) return NQ_ERR_UNSUPPORTED;   // 32-bit buffer offsets into x
   Conv3Args a;
   a.nsplit = nsplit; a.per_split = per_split; a.slab = slab;
   a.x = x; a.wt3 = wt3; a.bias = bias; a.y = y; a.z = z; a.zprev = zprev;
@@ -587,6 +631,7 @@ extern "C" int NQ_CAT(nq_conv_igemm3_k, NQ_KS)(const float* x, const void* wt3, 
   a.nchunk = (Cin + CC - 1) / CC;
   a.tail8 = (Cin - CC * (a.nchunk - 1)) <= 8 ? 1 : 0;
   a.co_tiles = (Cout + 16 * mi_sel - 1) / (16 * mi_sel);
+  a.w_bytes = (unsigned)(((int64_t)(a.nchunk - 1) * NST + (a.tail8 ? NST8 : NST)) * 2 * a.co_tiles * 4 * (16 * mi_sel) * 16);
   const int tiles = a.tiles_x * ((H + TH - 1) / TH);
   switch (mi_sel) {
     case 1: return launch_igemm3<1>(a, tiles, st);
