@@ -56,9 +56,16 @@ struct Conv3Args {
 
 // Timing experiments only (never in the product build): -DNQ_IG3_ABL=n compiles the kernel WITHOUT one of its parts
 // (results are wrong): 1 patch global loads, 2 patch conversion + LDS stores, 3 the MFMAs, 4 the epilogue's global
-// traffic, 5 weight global loads + LDS stores, 6 the B-fragment LDS reads (tools/ablate_igemm3.sh).
+// traffic, 5 weight LDS stores, 6 the B-fragment LDS reads, 7 patch loads confined to a 256 KiB window (L2 hits)
+// (tools/ablate_igemm3.sh).
 #ifndef NQ_IG3_ABL
 #define NQ_IG3_ABL 0
+#endif
+#ifndef NQ_IG3_SPREAD
+#define NQ_IG3_SPREAD 1
+#endif
+#ifndef NQ_IG3_PSTD
+#define NQ_IG3_PSTD 3   // the next chunk's patch loads are issued this many k-steps before the chunk ends
 #endif
 constexpr int KS = NQ_KS;
 constexpr int KK = KS * KS;
@@ -157,20 +164,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const bool x_edge = (x0 == 0) || (x0 + TW + PAD > W);   // block-uniform: some halo columns are outside the image
   f32x4 pv[8];
   u32x4 wvA[WPT], wvB[WPT];
-#define NQ3_LOAD_PATCH(CH)                                                                            \
+#define NQ3_LOAD_PATCH_J(CH, J)                                                                       \
   {                                                                                                   \
     /* channels of this item's octet that exist (0 for a thread without an item / a row outside the image): the   \
        offsets are selected with bit masks, not with ?: -- a conditional here comes back as a branch around the load */ \
     const int nv_ = (NQ_IG3_ABL != 1 && it_row) ? min(max(Cin - ((CH) * CC + it_oct * 8), 0), 8) : 0;  \
-    const unsigned first_ = ((CH) == 0 && it_neg) ? 0u : 0xFFFFFFFFu;                                 \
-    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                   \
-      unsigned o_ = (unsigned)it_base + (unsigned)((CH) * CC + j) * HWb;                              \
-      if (j == 0) o_ &= first_;                                                                       \
-      const unsigned sel_ = (unsigned)((j - nv_) >> 31);   /* all ones when j < nv_ */                  \
-      const unsigned off_ = (o_ & sel_) | (OOB & ~sel_);                                              \
-      pv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off_, 0, 0));     \
-    }                                                                                                 \
+    unsigned o_ = (unsigned)it_base + (unsigned)((CH) * CC + (J)) * HWb;                              \
+    if ((J) == 0 && (CH) == 0 && it_neg) o_ = 0u;                                                     \
+    if (NQ_IG3_ABL == 7) o_ &= 0x3FFF0u;   /* timing only: every patch load hits a 256 KiB window (L2) */ \
+    const unsigned sel_ = (unsigned)(((J) - nv_) >> 31);   /* all ones when J < nv_ */                  \
+    const unsigned off_ = (o_ & sel_) | (OOB & ~sel_);                                                \
+    pv[J] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, off_, 0, 0));       \
   }
+#define NQ3_LOAD_PATCH(CH)                                                                            \
+  { _Pragma("unroll") for (int j = 0; j < 8; ++j) NQ3_LOAD_PATCH_J(CH, j) }
 #define NQ3_STORE_PATCH(DST)                                                                          \
   if (NQ_IG3_ABL != 2 && it_act) {                                                                    \
     if (x_edge) {                                                                                     \
@@ -278,9 +285,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       }
       if constexpr (!TAIL) {
-        constexpr int pst = (NST >= 3) ? NST - 3 : 0;
-        if constexpr (st == pst) {   // past the last chunk of the tensor the channels are >= Cin: nothing is fetched
-          NQ3_LOAD_PATCH(ch + 1)
+        // The next chunk's 8 patch loads are SPREAD over the first NST - NQ_IG3_PSTD k-steps: a wave's loads return in
+        // order, so the weight loads of the following steps queue behind whatever patch loads were issued before them
+        // (past the last chunk of the tensor the channels are >= Cin: nothing is fetched)
+        constexpr int LS = (NST > NQ_IG3_PSTD) ? NST - NQ_IG3_PSTD : 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if ((NQ_IG3_SPREAD ? (j * LS) / 8 : LS - 1) == st) NQ3_LOAD_PATCH_J(ch + 1, j)
         }
       }
       const u32x4* __restrict__ pbt;
