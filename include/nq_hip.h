@@ -234,6 +234,17 @@ int nq_l2_loss(const float* pred, const float* tgt, float* loss, float* dpred, f
  * ws: >= 512*C floats.  Deterministic. */
 int nq_channel_sum(const float* x, float* out, float* ws, int B, int C, int64_t HW, nq_stream_t stream);
 
+/* nq_l2_loss + nq_tanh_out_backward + nq_channel_sum of a tanh-headed decoder in one pass over the image (the tail of
+ * calib_model.py:219-226 for OutImg 'tanh', models/_layers.py): loss[0] as nq_l2_loss (bit-identical), dconv (B,C,H,W) =
+ * [2*(pred-tgt)/(B*H*W)*gscale] * 0.5 * (1 - (2*pred-1)^2) = the gradient at the head conv's output, db[c] = sum of dconv
+ * over frames and pixels (the head's bias gradient).  The target is either float frames `tgt` (B,C,H,W) or the uint8
+ * frame cache `cache_u8` (N,C,H,W) with frame indices idx[B] (tgt = cache[idx]/255, videosets/datasets.py:19-24);
+ * exactly one of the two is non-NULL.  ws: >= 2*nq_reduce_ws_floats(B*C*HW) floats.  NQ_ERR_UNSUPPORTED unless
+ * HW % 4096 == 0 (callers then use the three separate entry points).  Deterministic. */
+int nq_l2_loss_tanh_head(const float* pred, const float* tgt, const uint8_t* cache_u8, const int64_t* idx, float* loss,
+                         float* dconv, float* db, float* ws, int B, int C, int64_t HW, int64_t mean_count, float gscale,
+                         nq_stream_t stream);
+
 /* Per-frame PSNR pieces (utils.py:148-151): sse[f] = sum over one frame of (out-gt)^2, frames of frame_len floats. */
 int nq_frame_sse(const float* out, const float* gt, float* sse, int64_t frames, int64_t frame_len, nq_stream_t stream);
 

@@ -85,6 +85,7 @@ def _load():
     sig("nq_tanh_out_backward", I, P, P, P, L, P)
     sig("nq_l2_loss", I, P, P, P, P, P, L, L, F, P)
     sig("nq_channel_sum", I, P, P, P, I, I, L, P)
+    sig("nq_l2_loss_tanh_head", I, P, P, P, P, P, P, P, P, I, I, L, L, F, P)
     sig("nq_frame_sse", I, P, P, P, L, L, P)
     sig("nq_gather_frames_u8", I, P, P, P, L, L, P)
     return lib
@@ -97,7 +98,7 @@ EXPORTS = (
     "nq_conv3_supported", "nq_conv3_weight_bytes", "nq_weight_layout3", "nq_weight_layout3_multi", "nq_conv_forward3_ws_floats", "nq_conv_forward3",
     "nq_conv_wgrad3_supported", "nq_conv_wgrad3_ws_floats", "nq_conv_wgrad3", "nq_conv_wgrad3_swapped",
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",
-    "nq_channel_sum", "nq_frame_sse", "nq_gather_frames_u8",
+    "nq_channel_sum", "nq_l2_loss_tanh_head", "nq_frame_sse", "nq_gather_frames_u8",
 )
 
 _lib = None

@@ -69,6 +69,66 @@ __global__ __launch_bounds__(TPB) void l2_loss_stage1(const float* __restrict__ 
   if (threadIdx.x == 0) ws[blockIdx.x] = s;
 }
 
+// lp_loss (p = 2) of a tanh-headed decoder in ONE pass: the loss partials (same chunks, same per-thread order as
+// l2_loss_stage1: the loss is bit-identical), the conv-output gradient of the head dconv = [gcoef*(pred-tgt)] * 0.5 *
+// (1 - t^2), t = 2*pred - 1 (the two roundings of l2_loss_stage1 followed by tanh_out_bwd_kernel), and per-chunk sums of
+// dconv (the head's bias gradient).  The target comes as float frames or straight from the uint8 frame cache
+// (frames[idx[b]] / 255, the arithmetic of gather_u8_kernel).  A chunk never straddles a channel plane (HW % chunk == 0).
+template <bool U8>
+__global__ __launch_bounds__(TPB) void l2_tanh_head_stage1(const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                           const uint8_t* __restrict__ cache, const int64_t* __restrict__ idx,
+                                                           float* __restrict__ dconv, float* __restrict__ ws, int64_t parts,
+                                                           int cpf /* chunks per frame = C*HW/chunk */, float gcoef) {
+  __shared__ float red[16];
+  const int64_t i0 = (int64_t)blockIdx.x * NQ_RED_CHUNK;
+  const uint8_t* __restrict__ src = nullptr;
+  if constexpr (U8) {
+    const int64_t f = blockIdx.x / cpf;
+    src = cache + idx[f] * ((int64_t)cpf * NQ_RED_CHUNK) + (int64_t)(blockIdx.x - f * cpf) * NQ_RED_CHUNK;
+  }
+  float acc = 0.f, accg = 0.f;
+#pragma unroll 4
+  for (int k = 0; k < NQ_RED_CHUNK / TPB; ++k) {
+    const int e = k * TPB + threadIdx.x;
+    const int64_t i = i0 + e;
+    const float p = pred[i];
+    const float t = U8 ? (float)src[e] / 255.f : tgt[i];
+    const float d = p - t;
+    acc += d * d;
+    const float g = gcoef * d;
+    const float u = 2.f * p - 1.f;
+    const float r = g * 0.5f * (1.f - u * u);
+    dconv[i] = r;
+    accg += r;
+  }
+  const float s = nq_block_sum(acc, red);
+  const float sg = nq_block_sum(accg, red);
+  if (threadIdx.x == 0) {
+    ws[blockIdx.x] = s;
+    ws[parts + blockIdx.x] = sg;
+  }
+}
+// block 0: the loss (as nq_sum_stage2); block 1 + c: db[c] = sum over frames and chunks of channel c, fixed order
+__global__ __launch_bounds__(256) void l2_tanh_head_stage2(const float* __restrict__ ws, int64_t parts, float scale,
+                                                           float* __restrict__ loss, float* __restrict__ db, int B, int C,
+                                                           int cpp /* chunks per plane */) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  if (blockIdx.x == 0) {
+    for (int64_t i = threadIdx.x; i < parts; i += 256) acc += ws[i];
+    const float s = nq_block_sum(acc, red);
+    if (threadIdx.x == 0) loss[0] = 0.f + s * scale;
+  } else {
+    const int c = blockIdx.x - 1;
+    for (int b = 0; b < B; ++b) {
+      const float* p = ws + parts + ((int64_t)b * C + c) * cpp;
+      for (int j = threadIdx.x; j < cpp; j += 256) acc += p[j];
+    }
+    const float s = nq_block_sum(acc, red);
+    if (threadIdx.x == 0) db[c] = s;
+  }
+}
+
 __global__ __launch_bounds__(1024) void frame_sse_kernel(const float* __restrict__ out, const float* __restrict__ gt,
                                                          float* __restrict__ sse, int64_t frame_len) {
   __shared__ float red[16];
@@ -157,6 +217,27 @@ int nq_l2_loss(const float* pred, const float* tgt, float* loss, float* dpred, f
   hipLaunchKernelGGL(l2_loss_stage1, dim3((unsigned)parts), dim3(TPB), 0, nq_s(stream), pred, tgt, dpred, ws, n, gcoef);
   hipLaunchKernelGGL(nq_sum_stage2, dim3(1), dim3(256), 0, nq_s(stream), ws, parts, (float)(1.0 / (double)mean_count),
                      loss, 0);
+  return nq_launch_status();
+}
+
+int nq_l2_loss_tanh_head(const float* pred, const float* tgt, const uint8_t* cache_u8, const int64_t* idx, float* loss,
+                         float* dconv, float* db, float* ws, int B, int C, int64_t HW, int64_t mean_count, float gscale,
+                         nq_stream_t stream) {
+  if (!pred || !loss || !dconv || !db || !ws || B <= 0 || C <= 0 || HW <= 0 || mean_count <= 0) return NQ_ERR_INVALID;
+  if ((tgt == nullptr) == (cache_u8 == nullptr) || (cache_u8 && !idx)) return NQ_ERR_INVALID;
+  if (HW % NQ_RED_CHUNK != 0 || C > 1024) return NQ_ERR_UNSUPPORTED;   // a chunk must stay inside one channel plane
+  const int64_t n = (int64_t)B * C * HW, parts = n / NQ_RED_CHUNK;
+  const int cpp = (int)(HW / NQ_RED_CHUNK), cpf = C * cpp;
+  if (parts > 0x7fffffffLL) return NQ_ERR_UNSUPPORTED;
+  const float gcoef = (float)(2.0 / (double)mean_count) * gscale;
+  if (cache_u8)
+    hipLaunchKernelGGL(l2_tanh_head_stage1<true>, dim3((unsigned)parts), dim3(TPB), 0, nq_s(stream), pred, tgt, cache_u8, idx,
+                       dconv, ws, parts, cpf, gcoef);
+  else
+    hipLaunchKernelGGL(l2_tanh_head_stage1<false>, dim3((unsigned)parts), dim3(TPB), 0, nq_s(stream), pred, tgt, cache_u8, idx,
+                       dconv, ws, parts, cpf, gcoef);
+  hipLaunchKernelGGL(l2_tanh_head_stage2, dim3((unsigned)(1 + C)), dim3(256), 0, nq_s(stream), ws, parts,
+                     (float)(1.0 / (double)mean_count), loss, db, B, C, cpp);
   return nq_launch_status();
 }
 

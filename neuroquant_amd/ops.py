@@ -813,6 +813,7 @@ class _DecoderStackFn(Function):
                 x = _space_from_channels(x, *spec.fc_hw).contiguous()
         ctx.spec, ctx.metas, ctx.n = spec, metas, n
         ctx.save_for_backward(x, *saved_in, *saved_z)
+        _HEAD["img_ptr"], _HEAD["dconv"], _HEAD["db"] = (x.data_ptr() if spec.tanh_out else None), None, None
         return x
 
     @staticmethod
@@ -822,11 +823,16 @@ class _DecoderStackFn(Function):
         img, xs, zs = saved[0], saved[1:1 + n], saved[1 + n:]
         d_emb = None
         g = _dev(g_img, "grad")
-        if spec.tanh_out:
+        head_db = None
+        if spec.tanh_out and _HEAD["dconv"] is not None and _HEAD["dconv"].data_ptr() == g.data_ptr() \
+                and _HEAD["img_ptr"] == img.data_ptr():
+            dconv, head_db = g, _HEAD["db"]   # l2_loss_head_grad already went through the tanh (and summed the bias gradient)
+        elif spec.tanh_out:
             dconv = torch.empty_like(g)
             L.check(L.lib().nq_tanh_out_backward(_p(g), _p(img), _p(dconv), g.numel(), _stream()), "tanh_backward")
         else:
             dconv = g
+        _HEAD["img_ptr"], _HEAD["dconv"], _HEAD["db"] = None, None, None
         grads = [None] * (2 * n)
         # The weight gradients are off the critical path (only the data gradients chain): they run on a second HIP
         # stream so that their workgroups fill the partial last rounds ("tails") of the data-gradient kernels and the
@@ -861,6 +867,12 @@ class _DecoderStackFn(Function):
                 return conv_wgrad3_raw(x_in, dconv, cout, k, has_b, out=out)
             if spec.precision == "bf16x3" and not in_gelu and cout <= 4 and cin > 4 and cout * k * k <= 64 \
                     and conv_wgrad3_supported(Bx, cout, Hx, Wx, cin, k):
+                if l == n - 1 and has_b and head_db is not None:   # bias gradient handed over by l2_loss_head_grad
+                    dw, _ = conv_wgrad_swapped3(x_in, dconv, cout, k, False, out=out)
+                    if out is not None:
+                        out[1].copy_(head_db)
+                        return dw, out[1]
+                    return dw, head_db
                 return conv_wgrad_swapped3(x_in, dconv, cout, k, has_b, out=out)
             return conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu, out=out)
 
@@ -948,6 +960,44 @@ def l2_loss_and_grad(pred, tgt):
     L.check(L.lib().nq_l2_loss(_p(pred_d), _p(tgt), _p(loss), _p(dpred), _p(ws), n, n // pred_d.shape[1], 1.0, _stream()),
             "l2_loss")
     return loss, dpred
+
+
+# Hand-over of the fused loss tail to the decoder node: (output tensor of the last tanh-headed decoder_stack,
+# its conv-output gradient, its bias gradient).  _DecoderStackFn.forward records the image it returned; l2_loss_head_grad
+# fills the gradients; _DecoderStackFn.backward takes them when the incoming gradient IS that dconv tensor.
+_HEAD = {"img_ptr": None, "dconv": None, "db": None}
+
+
+def l2_loss_head_grad(pred, tgt=None, cache_u8=None, idx=None):
+    """lp_loss(pred, tgt, p=2) for `pred` = the image a tanh-headed `decoder_stack` just returned, fused with what its
+    backward does first: returns (loss, g) where `pred.backward(g)` continues at the head convolution -- g is the
+    gradient at the head conv's OUTPUT (tanh backward applied) and the head's bias gradient is handed over with it
+    (one pass over the image instead of loss + tanh backward + channel sums; the target can be read straight from the
+    uint8 frame cache).  Returns None when the fused kernel does not apply (the caller then uses l2_loss_and_grad)."""
+    pred_d = _dev(pred.detach(), "pred")
+    if _HEAD["img_ptr"] != pred_d.data_ptr() or pred_d.dim() != 4 or os.environ.get("NQ_FUSED_LOSS", "1") == "0":
+        return None
+    B, C, H, W = pred_d.shape
+    if (H * W) % 4096 != 0 or C > 1024:
+        return None
+    if cache_u8 is not None:
+        if not cache_u8.is_cuda or cache_u8.dtype != torch.uint8 or not cache_u8.is_contiguous() \
+                or tuple(cache_u8.shape[1:]) != (C, H, W) or idx.numel() != B:
+            raise RuntimeError("frame cache must be a contiguous uint8 GPU tensor of the image's shape")
+        idx = idx.to(device=pred_d.device, dtype=torch.int64).contiguous()
+    else:
+        tgt = _dev(tgt, "tgt")
+    n = pred_d.numel()
+    loss = torch.empty((), device=pred_d.device, dtype=torch.float32)
+    dconv = torch.empty_like(pred_d)
+    db = torch.empty(C, device=pred_d.device, dtype=torch.float32)
+    ws = torch.empty(2 * L.lib().nq_reduce_ws_floats(n), device=pred_d.device, dtype=torch.float32)
+    L.check(L.lib().nq_l2_loss_tanh_head(_p(pred_d), _p(tgt) if cache_u8 is None else None,
+                                         _p(cache_u8) if cache_u8 is not None else None,
+                                         _p(idx) if cache_u8 is not None else None, _p(loss), _p(dconv), _p(db), _p(ws),
+                                         B, C, H * W, n // C, 1.0, _stream()), "l2_loss_tanh_head")
+    _HEAD["dconv"], _HEAD["db"] = dconv, db
+    return loss, dconv
 
 
 def frame_psnr(out, gt):

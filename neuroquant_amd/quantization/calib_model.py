@@ -200,7 +200,16 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                     L.forward_uaq()
             ops.GRAD_ARENA_REDUCED = False
             img_out, _, _ = model(inputs)
-            rec, dimg = ops.l2_loss_and_grad(img_out, img)   # lp_loss p=2 (quantizer.py:66-71) and its gradient
+            # lp_loss p=2 (quantizer.py:66-71) and its gradient; behind a tanh-headed fused decoder the loss kernel also
+            # applies the tanh backward and sums the head's bias gradient (ops.l2_loss_head_grad), reading the target
+            # straight from the uint8 frame cache when the batch came as (frames_u8, indices)
+            fused = ops.l2_loss_head_grad(img_out, cache_u8=img[0], idx=img[1]) if isinstance(img, tuple) \
+                else ops.l2_loss_head_grad(img_out, tgt=img)
+            if fused is None:
+                if isinstance(img, tuple):
+                    img = ops.gather_frames_u8(img[0], img[1])
+                fused = ops.l2_loss_and_grad(img_out, img)
+            rec, dimg = fused
             img_out.backward(dimg)
             if dp and not ops.GRAD_ARENA_REDUCED:
                 # generic path (decoder not fused into one node): flatten, all-reduce, un-flatten
@@ -278,7 +287,7 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
 
             def static_batch():
                 ops.step_prologue(st['order'], st['scal'], st['step'], st['cur_idx'], st['cur_scal'])
-                return gt.cache.batch(st['cur_idx']), cali_data.index_select(0, st['cur_idx'])
+                return (gt.cache.frames, st['cur_idx']), cali_data.index_select(0, st['cur_idx'])
 
             for i in range(nb):
                 if step_hook is not None:
