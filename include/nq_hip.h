@@ -144,6 +144,16 @@ int nq_fwht(const float* x, float* y, int64_t outer, int n, int64_t inner, int n
 int nq_weight_layouts(const float* w, float* wt_fwd, float* wt_bwd, int Cout, int Cin, int k, int krows_fwd,
                       int ld_fwd, int krows_bwd, int ld_bwd, nq_stream_t stream);
 
+/* nq_weight_layouts for several layers in ONE launch (the per-layer form is launch-bound); `segs` is a host array, the
+ * pointers inside are device pointers; wt_fwd / wt_bwd may be NULL per segment; dims as for nq_weight_layouts. */
+typedef struct nq_wl_seg {
+  const float* w;
+  float* wt_fwd;
+  float* wt_bwd;
+  int Cout, Cin, k, krows_fwd, ld_fwd, krows_bwd, ld_bwd;
+} nq_wl_seg;
+int nq_weight_layouts_multi(const nq_wl_seg* segs, int nseg, nq_stream_t stream);
+
 /* Padded operand sizes the conv kernels expect for a (Cin -> Cout, k) convolution. */
 int nq_conv_operand_dims(int Cin, int Cout, int k, int* krows, int* ld);
 

@@ -28,6 +28,12 @@ class WL3Seg(Structure):
     _fields_ = [("w", c_void_p), ("wt3", c_void_p), ("Cin", c_int), ("Cout", c_int), ("k", c_int), ("transposed", c_int)]
 
 
+class WLSeg(Structure):
+    """nq_wl_seg (include/nq_hip.h)."""
+    _fields_ = [("w", c_void_p), ("wt_fwd", c_void_p), ("wt_bwd", c_void_p), ("Cout", c_int), ("Cin", c_int), ("k", c_int),
+                ("krows_fwd", c_int), ("ld_fwd", c_int), ("krows_bwd", c_int), ("ld_bwd", c_int)]
+
+
 class AdamSeg(Structure):
     """nq_adam_seg (include/nq_hip.h)."""
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64)]
@@ -73,6 +79,7 @@ def _load():
     sig("nq_conv3_weight_bytes", L, I, I, I)
     sig("nq_weight_layout3", I, P, P, I, I, I, I, P)
     sig("nq_weight_layout3_multi", I, POINTER(WL3Seg), I, P)
+    sig("nq_weight_layouts_multi", I, POINTER(WLSeg), I, P)
     sig("nq_conv_forward3_ws_floats", L, I, I, I, I, I, I)
     sig("nq_conv_forward3", I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P)
     sig("nq_conv_wgrad3_supported", I, I, I, I, I, I, I)
@@ -95,7 +102,7 @@ EXPORTS = (
     "nq_abi_version", "nq_error_string", "nq_scale_init_max", "nq_uaq_forward", "nq_uaq_backward",
     "nq_adaround_init", "nq_adaround_forward", "nq_adaround_backward", "nq_reduce_ws_floats", "nq_round_loss", "nq_round_loss_backward",
     "nq_adam_step", "nq_adaround_forward_multi", "nq_adaround_backward_multi", "nq_adam_step_multi", "nq_step_prologue", "nq_adaround_backward_multi_dyn", "nq_adam_step_multi_dyn", "nq_fwht", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
-    "nq_conv3_supported", "nq_conv3_weight_bytes", "nq_weight_layout3", "nq_weight_layout3_multi", "nq_conv_forward3_ws_floats", "nq_conv_forward3",
+    "nq_conv3_supported", "nq_conv3_weight_bytes", "nq_weight_layout3", "nq_weight_layout3_multi", "nq_weight_layouts_multi", "nq_conv_forward3_ws_floats", "nq_conv_forward3",
     "nq_conv_wgrad3_supported", "nq_conv_wgrad3_ws_floats", "nq_conv_wgrad3", "nq_conv_wgrad3_swapped",
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",
     "nq_channel_sum", "nq_l2_loss_tanh_head", "nq_frame_sse", "nq_gather_frames_u8",

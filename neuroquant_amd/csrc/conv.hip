@@ -135,6 +135,37 @@ __global__ __launch_bounds__(256) void weight_bwd_layout_kernel(const float* __r
   wt[i] = v;
 }
 
+// Both fp32 operands of several layers in ONE launch (the per-layer kernels above are launch-bound: five ~5 us launches per
+// iteration for the layers that stay on the fp32 kernels).  Flat element index per segment; same values as the two
+// kernels above.
+constexpr int WL_MAXSEG = 16;
+struct WLSeg {
+  const float* w;
+  float* wt;
+  int Cout, Cin, KK, krows, ld, bwd;
+};
+struct WLMulti {
+  WLSeg s[WL_MAXSEG];
+  int blk0[WL_MAXSEG + 1];
+  int nseg;
+};
+__global__ __launch_bounds__(256) void weight_layouts_multi_kernel(WLMulti t) {
+  int k = 0;
+  while (k + 1 < t.nseg && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
+  const WLSeg& g = t.s[k];
+  const int64_t i = (int64_t)(blockIdx.x - t.blk0[k]) * 256 + threadIdx.x;
+  if (i >= (int64_t)g.krows * g.ld) return;
+  const int row = (int)(i / g.ld), col = (int)(i - (int64_t)row * g.ld);
+  float v = 0.f;
+  if (g.bwd) {   // wt[(co*KK + tap')][ci] = w[co][ci][KK-1-tap']
+    const int co = row / g.KK, tap = row - co * g.KK;
+    if (co < g.Cout && col < g.Cin) v = g.w[((int64_t)co * g.Cin + col) * g.KK + (g.KK - 1 - tap)];
+  } else {       // wt[k][co] = w[co][k]
+    if (col < g.Cout && row < g.Cin * g.KK) v = g.w[(int64_t)col * (g.Cin * g.KK) + row];
+  }
+  g.wt[i] = v;
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ slab_db,
                                                            float* __restrict__ dw, float* __restrict__ db, int Cout, int N,
                                                            int co_pad, int n_pad, int nsplit) {
@@ -184,6 +215,38 @@ int nq_weight_layouts(const float* w, float* wt_fwd, float* wt_bwd, int Cout, in
     hipLaunchKernelGGL(weight_bwd_layout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nq_s(stream), w,
                        wt_bwd, Cout, Cin, KK, krows_bwd, ld_bwd);
   }
+  return nq_launch_status();
+}
+
+int nq_weight_layouts_multi(const nq_wl_seg* segs, int nseg, nq_stream_t stream) {
+  if (!segs || nseg <= 0) return NQ_ERR_INVALID;
+  WLMulti t;
+  t.nseg = 0;
+  int blocks = 0;
+  auto flush = [&]() {
+    if (t.nseg == 0) return;
+    t.blk0[t.nseg] = blocks;
+    hipLaunchKernelGGL(weight_layouts_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, nq_s(stream), t);
+    t.nseg = 0;
+    blocks = 0;
+  };
+  for (int i = 0; i < nseg; ++i) {
+    const nq_wl_seg& h = segs[i];
+    if (!h.w || h.Cout <= 0 || h.Cin <= 0 || h.k <= 0) return NQ_ERR_INVALID;
+    const int KK = h.k * h.k;
+    for (int bwd = 0; bwd < 2; ++bwd) {
+      float* wt = bwd ? h.wt_bwd : h.wt_fwd;
+      if (!wt) continue;
+      const int krows = bwd ? h.krows_bwd : h.krows_fwd, ld = bwd ? h.ld_bwd : h.ld_fwd;
+      if (bwd ? (krows < h.Cout * KK || ld < h.Cin) : (krows < h.Cin * KK || ld < h.Cout)) return NQ_ERR_INVALID;
+      if (t.nseg == WL_MAXSEG) flush();
+      t.s[t.nseg] = WLSeg{h.w, wt, h.Cout, h.Cin, KK, krows, ld, bwd};
+      t.blk0[t.nseg] = blocks;
+      blocks += (int)(((int64_t)krows * ld + 255) / 256);
+      ++t.nseg;
+    }
+  }
+  flush();
   return nq_launch_status();
 }
 

@@ -378,6 +378,29 @@ def weight_layouts(w, need_bwd):
     return wt, (kf, lf), wb, (kb, lb)
 
 
+def weight_layouts_multi(items):
+    """items: [(w, need_fwd, need_bwd)] -> [(wt_fwd | None, dims_fwd, wt_bwd | None, dims_bwd)] as weight_layouts, ONE launch."""
+    segs = (L.WLSeg * len(items))()
+    outs = []
+    for sg, (w, need_fwd, need_bwd) in zip(segs, items):
+        w = _dev(w)
+        cout, cin, k, _ = w.shape
+        wt = wb = None
+        kf = lf = kb = lb = 0
+        if need_fwd:
+            kf, lf = conv_operand_dims(cin, cout, k)
+            wt = torch.empty(kf * lf, device=w.device, dtype=torch.float32)
+        if need_bwd:
+            kb, lb = conv_operand_dims(cout, cin, k)
+            wb = torch.empty(kb * lb, device=w.device, dtype=torch.float32)
+        sg.w, sg.wt_fwd, sg.wt_bwd, sg.Cout, sg.Cin, sg.k = _p(w), _p(wt), _p(wb), cout, cin, k
+        sg.krows_fwd, sg.ld_fwd, sg.krows_bwd, sg.ld_bwd = kf, lf, kb, lb
+        outs.append((wt, (kf, lf), wb, (kb, lb)))
+    if items:
+        L.check(L.lib().nq_weight_layouts_multi(segs, len(items), _stream()), "weight_layouts_multi")
+    return outs
+
+
 def conv_forward_raw(x, wt, dims, bias, cout, k, epilogue, r, in_gelu=False, zprev=None):
     """One nq_conv_forward launch.  Returns (y, z): z = shuffled pre-activation for the PixelShuffle epilogues
     (y is None for EPI_PS), y = un-shuffled gradient for EPI_DGRAD_GELU."""
@@ -770,23 +793,26 @@ class _DecoderStackFn(Function):
                 Hx, Wx = Hx * spec.fc_hw[0], Wx * spec.fc_hw[1]
             Hx, Wx = Hx * r, Wx * r
         operands = weight_layout3_multi(items)
+        # the fp32 operands (layers / directions that stay on the fp32 kernels), all from ONE launch as well.
+        # layer 0's data-gradient operand is only needed when the embedding itself is trained (FP32 trainer: the
+        # ConvNeXt encoder sits below it, reference regress.py:259-266)
+        need_bs = [(l > 0 and not plan[l][1]) or (l == 0 and ctx.needs_input_grad[0]) for l in range(n)]
+        fp32_items = [(_dev(wb[2 * l], "weight"), not plan[l][0], need_bs[l]) for l in range(n)
+                      if (not plan[l][0]) or need_bs[l]]
+        fp32_ops = iter(weight_layouts_multi(fp32_items))
         for l, (k, r, act) in enumerate(spec.layers):
             W = _dev(wb[2 * l], "weight")
             b = _dev(wb[2 * l + 1], "bias") if wb[2 * l + 1] is not None else None
             cout, cin = W.shape[0], W.shape[1]
             use3, use3_bwd, i_f, i_b = plan[l]
-            # layer 0's data-gradient operand is only needed when the embedding itself is trained (FP32 trainer: the
-            # ConvNeXt encoder sits below it, reference regress.py:259-266)
-            need_b = (l > 0 and not use3_bwd) or (l == 0 and ctx.needs_input_grad[0])
+            need_b = need_bs[l]
             wt = dims = wbk = dims_b = None
             if use3:
                 wt3 = operands[i_f]
-                if need_b:
-                    _, _, wbk, dims_b = weight_layouts(W, need_bwd=True)
-            elif need_b:   # both fp32 operands of this layer from ONE launch
-                wt, dims, wbk, dims_b = weight_layouts(W, need_bwd=True)
-            else:
-                wt, dims, _, _ = weight_layouts(W, need_bwd=False)
+            if (not use3) or need_b:
+                wt, dims, wbk, dims_b = next(fp32_ops)
+                if not need_b:
+                    wbk = dims_b = None
             last = l == n - 1
             if last:
                 epi = EPI_TANH if spec.tanh_out else EPI_PLAIN
