@@ -889,6 +889,55 @@ def test_multi_tensor_kernels_equal_single_tensor_ones(ops):
         assert torch.equal(a, b)
 
 
+def test_weight_layouts_multi_equals_single(ops):
+    """nq_weight_layouts_multi (both fp32 operands of several layers, one launch, > 16 segments = chunked) vs nq_weight_layouts."""
+    g = torch.Generator().manual_seed(5)
+    shapes = [(92, 16, 1, 1), (37, 5, 3, 3), (148, 44, 5, 5), (3, 37, 3, 3), (16, 1024, 3, 3)] * 4
+    ws = [torch.randn(s, generator=g).to(DEV) for s in shapes]
+    items = [(w, i % 3 != 1, i % 3 != 0) for i, w in enumerate(ws)]   # fwd only / bwd only / both
+    for (w, nf, nb), (wt, dims, wb, dims_b) in zip(items, ops.weight_layouts_multi(items)):
+        rt, rd, rb, rdb = ops.weight_layouts(w, need_bwd=True)
+        assert (wt is None) == (not nf) and (wb is None) == (not nb)
+        if nf:
+            assert dims == rd and torch.equal(wt, rt)
+        if nb:
+            assert dims_b == rdb and torch.equal(wb, rb)
+
+
+@pytest.mark.parametrize("u8", [False, True])
+def test_fused_loss_tail_equals_separate_kernels(ops, u8):
+    """nq_l2_loss_tanh_head (loss + tanh backward + head bias gradient [+ uint8 target gather], one pass) vs
+    nq_l2_loss -> nq_tanh_out_backward -> nq_channel_sum [<- nq_gather_frames_u8]: loss and dconv bit-identical, the
+    bias gradient is the same sum in another (fixed) order.  Only offered behind a tanh-headed decoder_stack and for
+    H*W % 4096 == 0; otherwise the caller gets None and uses the separate entry points."""
+    g = torch.Generator().manual_seed(9)
+    B, C, H, W = 3, 3, 64, 128
+    pred = torch.rand(B, C, H, W, generator=g).to(DEV)
+    cache = torch.randint(0, 256, (7, C, H, W), generator=g, dtype=torch.uint8).to(DEV)
+    idx = torch.tensor([5, 0, 3], device=DEV)
+    tgt = ops.gather_frames_u8(cache, idx)
+    assert ops.l2_loss_head_grad(pred, tgt=tgt) is None          # not the output of a decoder_stack
+    ops._HEAD["img_ptr"] = pred.data_ptr()                        # what _DecoderStackFn.forward records
+    loss, dconv = ops.l2_loss_head_grad(pred, cache_u8=cache, idx=idx) if u8 else ops.l2_loss_head_grad(pred, tgt=tgt)
+    db = ops._HEAD["db"]
+    rl, dimg = ops.l2_loss_and_grad(pred, tgt)
+    rdconv = torch.empty_like(dimg)
+    L = ops.L
+    L.check(L.lib().nq_tanh_out_backward(ops._p(dimg), ops._p(pred), ops._p(rdconv), dimg.numel(), ops._stream()), "tanh")
+    assert torch.equal(loss, rl) and torch.equal(dconv, rdconv)
+    close(db, ops.channel_sum(rdconv), rtol=2e-5, atol=1e-9)
+    close(db, rdconv.double().sum(dim=(0, 2, 3)), rtol=2e-5, atol=1e-9)
+    # the oracle's chain: lp_loss -> autograd through tanh*0.5+0.5
+    conv = torch.atanh((pred.cpu().double() * 2 - 1).clamp(-1 + 1e-12, 1 - 1e-12)).requires_grad_(True)
+    lo = O.lp_loss((torch.tanh(conv) * 0.5 + 0.5).float(), tgt.cpu())
+    close(loss, lo, rtol=1e-5)
+    ops._HEAD["img_ptr"], ops._HEAD["dconv"], ops._HEAD["db"] = None, None, None
+    odd = torch.rand(2, 3, 17, 23, generator=g).to(DEV)          # H*W % 4096 != 0 -> separate kernels
+    ops._HEAD["img_ptr"] = odd.data_ptr()
+    assert ops.l2_loss_head_grad(odd, tgt=torch.rand(2, 3, 17, 23, generator=g).to(DEV)) is None
+    ops._HEAD["img_ptr"] = None
+
+
 @pytest.mark.parametrize("arch,had", [("hnerv", False), ("nerv", True)])
 def test_gradient_arena_hook_is_transparent(ops, golden, arch, had):
     """Data-parallel plumbing on one GPU: with a gradient-arena hook installed (what model_reconstruction does when
