@@ -56,10 +56,14 @@ struct Conv3Args {
 
 // Timing experiments only (never in the product build): -DNQ_IG3_ABL=n compiles the kernel WITHOUT one of its parts
 // (results are wrong): 1 patch global loads, 2 patch conversion + LDS stores, 3 the MFMAs, 4 the epilogue's global
-// traffic, 5 weight LDS stores, 6 the B-fragment LDS reads, 7 patch loads confined to a 256 KiB window (L2 hits)
+// traffic, 5 weight LDS stores, 6 the B-fragment LDS reads, 7 patch loads confined to a 256 KiB window (L2 hits),
+// 8 no patch re-staging after the first chunk, 9 no weight staging after the prologue, 10 both (operands stay random)
 // (tools/ablate_igemm3.sh).
 #ifndef NQ_IG3_ABL
 #define NQ_IG3_ABL 0
+#endif
+#ifndef NQ_IG3_R4MIN
+#define NQ_IG3_R4MIN 5   // smallest MI that keeps its weights in a ring of four LDS buffers (one barrier per two k-steps)
 #endif
 #ifndef NQ_IG3_SPREAD
 #define NQ_IG3_SPREAD 1
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   u32x4* const patch0 = smem;                  // 1 buffer of PATCH_U4 (re-filled between two barriers per chunk)
   // R4: ring of 4 weight buffers with one barrier per TWO k-steps (measured in one process, per-step barrier -> ring: the
   // 80-channel tile -10 %, the 48/64-channel tiles +2..3 % -- so only MI = 5 takes it); else 2 buffers, barrier per step
-  constexpr bool R4 = (MI >= 5);
+  constexpr bool R4 = (MI >= NQ_IG3_R4MIN);
   constexpr int WMASK = R4 ? 3 : 1;
   u32x4* const wl0 = smem + PATCH_U4;          // weight buffers of W_U4: k-step g lives in buffer g & WMASK
 
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       constexpr int st = decltype(st_c)::value;
       constexpr int gp = (PAR + st) & 1;  // parity of the global step
       const int g = g0 + st;
-      if constexpr (!R4) {
+      if constexpr (!R4 && NQ_IG3_ABL != 9 && NQ_IG3_ABL != 10) {   // ablations 9 / 10: the weights of the first steps for all
         if constexpr (gp == 0) {
           NQ3_LOAD_W(wvA, g + 2)
         } else {
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr int LS = (NST > NQ_IG3_PSTD) ? NST - NQ_IG3_PSTD : 1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          if ((NQ_IG3_SPREAD ? (j * LS) / 8 : LS - 1) == st) NQ3_LOAD_PATCH_J(ch + 1, j)
+          if (NQ_IG3_ABL != 8 && NQ_IG3_ABL != 10 && (NQ_IG3_SPREAD ? (j * LS) / 8 : LS - 1) == st) NQ3_LOAD_PATCH_J(ch + 1, j)
         }
       }
       const u32x4* __restrict__ pbt;
@@ -346,7 +350,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if constexpr (mi == (MI - 1) / 2) {
           // publish the next weights in the MIDDLE of the MFMA block (the LDS write latency is covered by the remaining
           // MFMAs instead of sitting in front of the barrier)
-          if constexpr (R4) {   // step g+2 from set g & 1, which is then re-armed with the loads of step g+4
+          if constexpr (NQ_IG3_ABL == 9 || NQ_IG3_ABL == 10) {
+          } else if constexpr (R4) {   // step g+2 from set g & 1, which is then re-armed with the loads of step g+4
             if (g + 2 < G) {
               u32x4* wdst = wl0 + ((g + 2) & 3) * W_U4;
               if constexpr (gp == 0) {
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
       });
       if constexpr (!TAIL && st == NST - 1) {
-        if (ch + 1 < nchunk) {
+        if (NQ_IG3_ABL != 8 && NQ_IG3_ABL != 10 && ch + 1 < nchunk) {   // ablations 8 / 10: every chunk re-uses the first patch
           __syncthreads();  // every wave is done with the current patch
           NQ3_STORE_PATCH(patch0)
         }
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int MI>
 int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
   constexpr int MT = 16 * MI;
-  size_t lds = (size_t)(PATCH_U4 + (MI >= 5 ? 4 : 2) * 2 * 4 * MT) * 16;   // patch + weight buffers (ring of 4 for MI = 5)
+  size_t lds = (size_t)(PATCH_U4 + (MI >= NQ_IG3_R4MIN ? 4 : 2) * 2 * 4 * MT) * 16;   // patch + weight buffers (ring of 4 for MI = 5)
   Conv3Args a = a_in;
   a.lds_epi = 0;
   if (a.epi == NQ_EPI_DGRAD_GELU && a.nsplit == 1 && MI <= 4) {   // 4 waves x [MT][64] floats for the wide epilogue
