@@ -257,7 +257,10 @@ def test_conv_forward_backward(ops, case):
                                   (2, 20, 33, 100, 96, 3, "tanh", 1), (4, 9, 16, 64, 36, 3, "dgrad", 2),
                                   (2, 848, 40, 80, 64, 5, "dgrad", 4), (1, 200, 20, 40, 64, 5, "plain", 1),
                                   (2, 64, 48, 96, 144, 5, "psgelu", 3), (2, 40, 48, 96, 16, 5, "dgrad", 3),
-                                  (2, 30, 120, 240, 40, 5, "dgrad", 3)])
+                                  (2, 30, 120, 240, 40, 5, "dgrad", 3),
+                                  # last channel chunk in every tail mode (<= 4 / 5..8 / 9..12 channels), alone and behind full chunks
+                                  (2, 12, 32, 64, 48, 5, "plain", 1), (2, 36, 32, 64, 48, 3, "psgelu", 2),
+                                  (2, 7, 32, 64, 32, 5, "plain", 1), (2, 28, 32, 64, 80, 3, "plain", 1)])
 def test_conv_bf16x3(ops, case):
     """bf16x3 kernel (split operands on the BF16 matrix pipe) vs float64: error stays at the fp32 level (a few 1e-6
     relative to the output scale), forward epilogues and the data-gradient operand (transposed=True) included.  Grids
