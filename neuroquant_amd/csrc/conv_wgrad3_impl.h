@@ -35,9 +35,14 @@ struct Wgrad3Args {
   float* slab;     // [nsplit][co_pad][n_pad]
   float* slab_db;  // [nsplit][co_pad]
   int B, Cin, H, W, Cout, N, co_pad, n_pad, segs_x, nseg, nsplit;
-  int dbg;  // timing experiments only (NQ_WG3_DBG): 1 = load one x row of five, 2 = producers skip the conversion, 3 = consumers skip the MFMAs
 };
 
+// Timing experiments only (never in the product build): -DNQ_WG3_ABL=n compiles conv_wgrad3p_kernel WITHOUT one of its
+// parts (results are wrong): 1 = load one x row of five, 2 = producers skip the conversion + LDS stores, 3 = consumers
+// skip the MFMAs, 4 = one B fragment for all n-blocks, 5 = 2 + 4 (tools/ablate_igemm3.sh builds such libraries).
+#ifndef NQ_WG3_ABL
+#define NQ_WG3_ABL 0
+#endif
 constexpr int KS = NQ_KS;
 constexpr int KK = KS * KS;
 constexpr int PAD = KS / 2;
@@ -488,7 +493,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int i = 0; i < XPT4; ++i) {
         const int gy = y + (xrc[i] >> 12) - PAD;
-        const bool ok = (xlds[i] >= 0) && gy >= 0 && gy < H && (a.dbg != 1 || (xrc[i] >> 12) == PAD);
+        const bool ok = (xlds[i] >= 0) && gy >= 0 && gy < H && (NQ_WG3_ABL != 1 || (xrc[i] >> 12) == PAD);
         // a quad that starts before the very first element of the tensor (frame 0, channel 0, row 0, left halo) is loaded
         // from offset 0 and shifted into place in store_seg: a negative offset would make the whole load read as zero
         const unsigned off = ok ? (unsigned)max(x_base + xoff[i], 0) : OOB;
@@ -597,11 +602,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // no early exit inside the body, so the in-flight load count the compiler reasons about is the same on every path.
     for (int seg = seg_lo; seg < seg_hi; seg += 2) {
       // consumers work on buf0 (segment seg); segment seg+1 (set B) goes to buf1, then set B is re-armed with seg+3
-      if (seg + 1 < seg_hi && a.dbg != 2 && a.dbg != 5) store_seg(buf1, seg + 1, dvB, xvB);
+      if (seg + 1 < seg_hi && NQ_WG3_ABL != 2 && NQ_WG3_ABL != 5) store_seg(buf1, seg + 1, dvB, xvB);
       load_seg(min(seg + 3, seg_last), dvB, xvB);
       __syncthreads();
       // consumers work on buf1 (segment seg+1); segment seg+2 (set A) goes to buf0, set A re-armed with seg+4
-      if (seg + 2 < seg_hi && a.dbg != 2 && a.dbg != 5) store_seg(buf0, seg + 2, dvA, xvA);
+      if (seg + 2 < seg_hi && NQ_WG3_ABL != 2 && NQ_WG3_ABL != 5) store_seg(buf0, seg + 2, dvA, xvA);
       load_seg(min(seg + 4, seg_last), dvA, xvA);
       __syncthreads();
     }
@@ -682,7 +687,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr int ni = decltype(ni_c)::value;
         const bf16x8 bh = bh0, bl = bl0;
         if constexpr (ni + 1 < NI) {
-          if (a.dbg != 4 && a.dbg != 5) build_B(ni + 1, bh0, bl0);   // dbg 4 (timing only): one B fragment for all n-blocks
+          if (NQ_WG3_ABL != 4 && NQ_WG3_ABL != 5) build_B(ni + 1, bh0, bl0);   // ablation 4 (timing only): one B fragment for all n-blocks
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], bh, acc[mi][ni], 0, 0, 0);
@@ -694,9 +699,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   };
   for (int seg = seg_lo; seg < seg_hi; seg += 2) {   // pairs, two barriers per pair (mirrors the producers)
-    if (a.dbg != 3) compute(0);
+    if (NQ_WG3_ABL != 3) compute(0);
     __syncthreads();
-    if (seg + 1 < seg_hi && a.dbg != 3) compute(1);
+    if (seg + 1 < seg_hi && NQ_WG3_ABL != 3) compute(1);
     __syncthreads();
   }
   __builtin_amdgcn_s_setprio(0);
@@ -773,10 +778,6 @@ extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, 
   a.segs_x = (W + SEG - 1) / SEG;
   a.nseg = a.segs_x * H * B;
   a.nsplit = nsplit;
-  {
-    const char* e = std::getenv("NQ_WG3_DBG");
-    a.dbg = e ? atoi(e) : 0;
-  }
   if (pc) {   // producer / consumer variant (wide n-tiles only; the plan sized nsplit for one 8-wave workgroup per CU);
               // pc: 1 = one row x 32 pixels per segment, 12 / 14 = 2 / 4 rows x 32 pixels, 4 = one row x 128 pixels (head)
 #define NQ_WG3P(MI_, NI_)                                                                   \

@@ -2,6 +2,8 @@
 # Builds ablated copies of libnqhip.so (conv_igemm3 compiled with -DNQ_IG3_ABL=n; timing experiments, wrong results)
 # under tools/_ab/abl<n>/ -- run on the build container; then on the GPU box:
 #   for n in 0 1 2 3 4 5 6; do NQ_LIB=tools/_ab/abl$n/libnqhip.so python tools/bench_kernels.py --only igemm3; done
+# The weight-gradient kernel has the same kind of switch: compile conv_wgrad3_k{3,5}.hip with -DNQ_WG3_ABL=n
+# (conv_wgrad3_impl.h) and link the objects in the same way.
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 C=$R/neuroquant_amd/csrc

@@ -61,20 +61,12 @@ def main():
             def wg(pc, x=x, dy=dy, cout=cout, k=k):
                 os.environ["NQ_WGRAD3_PC"] = pc
                 return ops.conv_wgrad3_raw(x, dy, cout, k, True)
-            def wgd(d, wg=wg):
-                os.environ["NQ_WG3_DBG"] = d
-                r = wg("1")
-                os.environ["NQ_WG3_DBG"] = "0"
-                return r
             def wgs1(wg=wg):
                 os.environ["NQ_WGRAD3_SS"] = "1"
                 r = wg("1")
                 os.environ["NQ_WGRAD3_SS"] = "0"
                 return r
             var = {"4wave": lambda wg=wg: wg("0"), "pc seg32": wgs1, "prod/cons": lambda wg=wg: wg("1")}
-            if os.environ.get("NQ_BENCH_DBG"):
-                var.update({"pc x1row": lambda wgd=wgd: wgd("1"), "pc noconv": lambda wgd=wgd: wgd("2"), "pc nomfma": lambda wgd=wgd: wgd("3"),
-                            "pc oneB": lambda wgd=wgd: wgd("4"), "pc oneB+nc": lambda wgd=wgd: wgd("5")})
             cases.append((f"{name} wgrad3 {cin}x{cout}", flops, var))
     # head layer 37 -> 3, k3, 640x1280 (streaming VALU kernels)
     hx = torch.randn(2, 37, 640, 1280, generator=g).cuda()
