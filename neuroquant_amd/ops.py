@@ -745,9 +745,17 @@ _GRAD_ARENA_HOOK = None
 GRAD_ARENA_REDUCED = False   # set by the node when the hook ran (the caller then skips its own exchange)
 
 
-def set_grad_arena_hook(fn):
-    global _GRAD_ARENA_HOOK
+_GRAD_ARENA_TWO_PHASE = False
+
+
+def set_grad_arena_hook(fn, two_phase=False):
+    """fn(arena) is called once per backward with the flat gradient arena.  two_phase=True: the node first runs ALL data
+    gradients, then the weight gradients of the deep layers (most of the parameters, little work), calls
+    fn(arena[:split], False), runs the weight gradients of the last layers (most of the work, few parameters) and calls
+    fn(arena[split:], True): an asynchronous collective started by the first call overlaps the expensive kernels."""
+    global _GRAD_ARENA_HOOK, _GRAD_ARENA_TWO_PHASE
     _GRAD_ARENA_HOOK = fn
+    _GRAD_ARENA_TWO_PHASE = bool(two_phase) and fn is not None
 
 
 _SIDE_STREAMS = {}
@@ -902,8 +910,56 @@ class _DecoderStackFn(Function):
                 return conv_wgrad_swapped3(x_in, dconv, cout, k, has_b, out=out)
             return conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu, out=out)
 
-        for l in range(n - 1, -1, -1):
+        def dgrad(l, dconv):
+            """conv-output gradient of layer l -> conv-output gradient of layer l - 1 (l >= 1)"""
             k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
+            kp, rp, actp = spec.layers[l - 1]
+            epi_b, r_b, zp = (EPI_DGRAD_GELU, rp, zs[l]) if actp else (EPI_PLAIN, 1, None)
+            if not actp and rp != 1:
+                raise NotImplementedError("PixelShuffle without activation between decoder layers")
+            # the layer below ends in GELU: d(pre-activation) = dgrad * gelu'(z), stored as ITS conv-output gradient
+            if W3 is not None:
+                d, _ = conv3_forward_raw(dconv, W3, None, cin, k, epi_b, r_b, zprev=zp)   # W3 = pre-built transposed operand
+            else:
+                d, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, epi_b, r_b, zprev=zp)
+            if not actp and l == 1 and spec.fc_hw != (1, 1):
+                d = _channels_from_space(d, *spec.fc_hw).contiguous()
+            return d
+
+        def emb_grad(dconv):   # d(embedding): plain data gradient through layer 0 (no activation below it)
+            k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[0]
+            return conv_forward_raw(dconv, wbk, dims_b, None, cin, k, EPI_PLAIN, 1)[0]
+
+        global GRAD_ARENA_REDUCED
+        if arena is not None and _GRAD_ARENA_TWO_PHASE and n > 1:
+            # Data-parallel schedule: the data-gradient chain first, then the weight gradients of the deep layers (most
+            # of the parameters, a few per cent of the work) whose part of the arena is handed to the hook at once, then
+            # the last layers' weight gradients (>= 80 % of the weight-gradient flops) while that collective is in
+            # flight, then the rest of the arena.  Same kernels on the same operands as the single-GPU order: identical bits.
+            dcs = [None] * n
+            dcs[n - 1] = dconv
+            for l in range(n - 1, 0, -1):
+                dcs[l - 1] = dgrad(l, dcs[l])
+            if ctx.needs_input_grad[0]:
+                d_emb = emb_grad(dcs[0])
+            flops = [metas[l][3] * metas[l][4] * metas[l][0] ** 2 * xs[l].shape[2] * xs[l].shape[3] for l in range(n)]
+            split, late = n - 1, flops[n - 1]
+            while split > 1 and late < 0.8 * sum(flops):
+                split -= 1
+                late += flops[split]
+            for l in range(split):
+                grads[2 * l], grads[2 * l + 1] = wgrad(l, dcs[l])
+                dcs[l] = None
+            off = sum(sizes[:2 * split])
+            _GRAD_ARENA_HOOK(arena[:off], False)
+            for l in range(split, n):
+                grads[2 * l], grads[2 * l + 1] = wgrad(l, dcs[l])
+                dcs[l] = None
+            _GRAD_ARENA_HOOK(arena[off:], True)
+            GRAD_ARENA_REDUCED = True
+            return (d_emb, None) + tuple(grads)
+
+        for l in range(n - 1, -1, -1):
             if side is not None:
                 keep.append(dconv)
                 side.wait_stream(main)
@@ -916,25 +972,13 @@ class _DecoderStackFn(Function):
                 dw, db = wgrad(l, dconv)
             grads[2 * l], grads[2 * l + 1] = dw, db
             if l == 0:
-                if ctx.needs_input_grad[0]:   # d(embedding): plain data gradient through layer 0 (no activation below it)
-                    d_emb, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, EPI_PLAIN, 1)
+                if ctx.needs_input_grad[0]:
+                    d_emb = emb_grad(dconv)
                 break
-            kp, rp, actp = spec.layers[l - 1]
-            epi_b, r_b, zp = (EPI_DGRAD_GELU, rp, zs[l]) if actp else (EPI_PLAIN, 1, None)
-            if not actp and rp != 1:
-                raise NotImplementedError("PixelShuffle without activation between decoder layers")
-            # the layer below ends in GELU: d(pre-activation) = dgrad * gelu'(z), stored as ITS conv-output gradient
-            if W3 is not None:
-                dconv, _ = conv3_forward_raw(dconv, W3, None, cin, k, epi_b, r_b, zprev=zp)   # W3 = pre-built transposed operand
-            else:
-                dconv, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, epi_b, r_b, zprev=zp)
-            if not actp:
-                if l == 1 and spec.fc_hw != (1, 1):
-                    dconv = _channels_from_space(dconv, *spec.fc_hw).contiguous()
+            dconv = dgrad(l, dconv)
         if side is not None:
             main.wait_stream(side)
             keep.clear()
-        global GRAD_ARENA_REDUCED
         if arena is not None:
             _GRAD_ARENA_HOOK(arena)
             GRAD_ARENA_REDUCED = True

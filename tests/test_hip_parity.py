@@ -972,6 +972,25 @@ def test_gradient_arena_hook_is_transparent(ops, golden, arch, had):
     assert seen == [sum(t.numel() for t in base)]
     for a, b in zip(base, same):
         assert torch.equal(a, b)
+    # two-phase (data-parallel) schedule: all data gradients first, the arena handed over in two parts -- same bits
+    parts = []
+
+    def two(hook_grads=None):
+        qnn = QuantModel(_build(arch, sd), hadamard=had, weight_quant_params=dict(n_bits=8, channel_wise=True))
+        spec, provs = _decode._fused_stack(qnn.model)
+        g = torch.Generator().manual_seed(4)
+        ws = [tuple(t.detach().clone().requires_grad_(True) for t in p()) for p in provs]
+        ops.set_grad_arena_hook(lambda part, last: parts.append((part.numel(), last)), two_phase=True)
+        try:
+            out = ops.decoder_stack(emb, spec, ws)
+            (out * torch.randn(out.shape, generator=g).to(DEV)).sum().backward()
+        finally:
+            ops.set_grad_arena_hook(None)
+        return [t.grad.clone() for pair in ws for t in pair]
+
+    for a, b in zip(base, two()):
+        assert torch.equal(a, b)
+    assert [l for _, l in parts] == [False, True] and sum(n for n, _ in parts) == seen[0] and all(n > 0 for n, _ in parts)
     half = grads(lambda arena: arena.mul_(0.5))
     for a, b in zip(base, half):
         assert torch.equal(a * 0.5, b)
