@@ -5,6 +5,7 @@ the hot path runs in the hand-written gfx950 kernels; there is NO CPU / eager fa
 its tensors are not fp32 HIP tensors or if libnqhip.so is missing.
 """
 import ctypes
+import functools
 import math
 import os
 
@@ -12,6 +13,19 @@ import torch
 from torch.autograd import Function
 
 from . import _lib as L
+
+_QCACHE = {}
+
+
+def _q(name, *args):
+    """Pure shape queries of the library (supported / workspace size / operand size), memoised: ~40 ctypes round trips
+    per iteration otherwise.  The two environment switches that change a plan are part of the key (tools/bench_kernels.py
+    flips them between launches of one process)."""
+    key = (name, args, os.environ.get("NQ_WGRAD3_PC"), os.environ.get("NQ_WGRAD3_SS"))
+    v = _QCACHE.get(key)
+    if v is None:
+        v = _QCACHE[key] = getattr(L.lib(), name)(*args)
+    return v
 
 EPI_PLAIN, EPI_PS_GELU, EPI_TANH, EPI_PS, EPI_DGRAD_GELU = (L.EPI_PLAIN, L.EPI_PS_GELU, L.EPI_TANH, L.EPI_PS,
                                                                 L.EPI_DGRAD_GELU)
@@ -154,7 +168,7 @@ def adaround_backward(x, gy, alpha, delta, zp, n_levels, reg_weight=0.0, reg_b=0
 def round_loss(alpha, b, weight, out=None, accumulate=False):
     alpha = _dev(alpha)
     n = alpha.numel()
-    ws = torch.empty(L.lib().nq_reduce_ws_floats(n), device=alpha.device, dtype=torch.float32)
+    ws = torch.empty(_q("nq_reduce_ws_floats", n), device=alpha.device, dtype=torch.float32)
     if out is None:
         out = torch.zeros((), device=alpha.device, dtype=torch.float32)
     L.check(L.lib().nq_round_loss(_p(alpha), n, float(b), float(weight), _p(ws), _p(out), 1 if accumulate else 0, _stream()),
@@ -358,6 +372,7 @@ def hadamard_weight_of(w: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------ convolution
+@functools.lru_cache(maxsize=None)
 def conv_operand_dims(cin, cout, k):
     kr, ld = ctypes.c_int(0), ctypes.c_int(0)
     L.check(L.lib().nq_conv_operand_dims(cin, cout, k, ctypes.byref(kr), ctypes.byref(ld)), "conv_operand_dims")
@@ -414,7 +429,7 @@ def conv_forward_raw(x, wt, dims, bias, cout, k, epilogue, r, in_gelu=False, zpr
         y = torch.empty((B, cout * r * r, H // r, W // r), device=x.device, dtype=torch.float32)
     else:
         y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
-    nws = L.lib().nq_conv_forward_ws_floats(B, cin, H, W, cout, k)
+    nws = _q("nq_conv_forward_ws_floats", B, cin, H, W, cout, k)
     ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
     _timed(("conv_igemm", k, cin, cout, H, W, B, epilogue),
            lambda: L.check(L.lib().nq_conv_forward(_p(x), _p(wt), _p(bias), _p(y), _p(z), _p(ws), B, cin, H, W, cout, k,
@@ -424,7 +439,7 @@ def conv_forward_raw(x, wt, dims, bias, cout, k, epilogue, r, in_gelu=False, zpr
 
 
 def conv3_supported(B, cin, H, W, cout, k):
-    return bool(L.lib().nq_conv3_supported(B, cin, H, W, cout, k))
+    return bool(_q("nq_conv3_supported", B, cin, H, W, cout, k))
 
 
 def weight_layout3(w, transposed=False):
@@ -432,7 +447,7 @@ def weight_layout3(w, transposed=False):
     w = _dev(w)
     cw_out, cw_in, k, _ = w.shape
     cin, cout = (cw_out, cw_in) if transposed else (cw_in, cw_out)
-    buf = torch.empty(L.lib().nq_conv3_weight_bytes(cin, cout, k), device=w.device, dtype=torch.uint8)
+    buf = torch.empty(_q("nq_conv3_weight_bytes", cin, cout, k), device=w.device, dtype=torch.uint8)
     L.check(L.lib().nq_weight_layout3(_p(w), _p(buf), cin, cout, k, 1 if transposed else 0, _stream()), "weight_layout3")
     return buf
 
@@ -445,7 +460,7 @@ def weight_layout3_multi(items):
         w = _dev(w)
         cw_out, cw_in, k, _ = w.shape
         cin, cout = (cw_out, cw_in) if transposed else (cw_in, cw_out)
-        buf = torch.empty(L.lib().nq_conv3_weight_bytes(cin, cout, k), device=w.device, dtype=torch.uint8)
+        buf = torch.empty(_q("nq_conv3_weight_bytes", cin, cout, k), device=w.device, dtype=torch.uint8)
         outs.append(buf)
         sg.w, sg.wt3, sg.Cin, sg.Cout, sg.k, sg.transposed = _p(w), _p(buf), cin, cout, k, int(bool(transposed))
     if items:
@@ -465,7 +480,7 @@ def conv3_forward_raw(x, wt3, bias, cout, k, epilogue, r, zprev=None):
         y = torch.empty((B, cout * r * r, H // r, W // r), device=x.device, dtype=torch.float32)
     else:
         y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
-    nws = L.lib().nq_conv_forward3_ws_floats(B, cin, H, W, cout, k)
+    nws = _q("nq_conv_forward3_ws_floats", B, cin, H, W, cout, k)
     ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
     _timed(("conv_igemm3", k, cin, cout, H, W, B, epilogue),
            lambda: L.check(L.lib().nq_conv_forward3(_p(x), _p(wt3), _p(bias), _p(y), _p(z), _p(zprev), _p(ws), B, cin, H, W,
@@ -474,14 +489,14 @@ def conv3_forward_raw(x, wt3, bias, cout, k, epilogue, r, zprev=None):
 
 
 def conv_wgrad3_supported(B, cin, H, W, cout, k):
-    return bool(L.lib().nq_conv_wgrad3_supported(B, cin, H, W, cout, k))
+    return bool(_q("nq_conv_wgrad3_supported", B, cin, H, W, cout, k))
 
 
 def conv_wgrad3_raw(x, dy, cout, k, want_db, out=None):
     """bf16x3 counterpart of conv_wgrad_raw.  out = (dw, db) pre-allocated contiguous outputs (views of a flat
     gradient arena) or None."""
     B, cin, H, W = x.shape
-    ws = torch.empty(L.lib().nq_conv_wgrad3_ws_floats(B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
+    ws = torch.empty(_q("nq_conv_wgrad3_ws_floats", B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
     dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32) if out is None else out[0]
     db = (torch.empty(cout, device=x.device, dtype=torch.float32) if out is None else out[1]) if want_db else None
     _timed(("conv_wgrad3", k, cin, cout, H, W, B, 0),
@@ -506,7 +521,7 @@ def conv_wgrad_swapped3(x, dy, cout, k, want_db, out=None):
     read exactly once, only the 3-channel dy needs halo rows, and the MFMA tile is 37(->48) x 27(->64) instead of
     3(->16) x 333(->384)."""
     B, cin, H, W = x.shape
-    ws = torch.empty(L.lib().nq_conv_wgrad3_ws_floats(B, cout, H, W, cin, k), device=x.device, dtype=torch.float32)
+    ws = torch.empty(_q("nq_conv_wgrad3_ws_floats", B, cout, H, W, cin, k), device=x.device, dtype=torch.float32)
     dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32) if out is None else out[0]
     # the slab reduction writes dW[co][ci][K-1-kh][K-1-kw] directly (no permute / flip / copy passes)
     _timed(("conv_wgrad3", k, cout, cin, H, W, B, 0),
@@ -523,7 +538,7 @@ def conv_wgrad_swapped3(x, dy, cout, k, want_db, out=None):
 
 def conv_wgrad_raw(x, dy, cout, k, want_db, x_gelu=False, out=None):
     B, cin, H, W = x.shape
-    ws = torch.empty(L.lib().nq_conv_wgrad_ws_floats(B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
+    ws = torch.empty(_q("nq_conv_wgrad_ws_floats", B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
     dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32) if out is None else out[0]
     db = (torch.empty(cout, device=x.device, dtype=torch.float32) if out is None else out[1]) if want_db else None
     _timed(("conv_wgrad", k, cin, cout, H, W, B, 0),
@@ -1004,7 +1019,7 @@ class _L2LossFn(Function):
         mean_count = n // pred.shape[1]
         loss = torch.empty((), device=pred.device, dtype=torch.float32)
         dpred = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
-        ws = torch.empty(L.lib().nq_reduce_ws_floats(n), device=pred.device, dtype=torch.float32)
+        ws = torch.empty(_q("nq_reduce_ws_floats", n), device=pred.device, dtype=torch.float32)
         L.check(L.lib().nq_l2_loss(_p(pred), _p(tgt), _p(loss), _p(dpred), _p(ws), n, mean_count, 1.0, _stream()), "l2_loss")
         ctx.save_for_backward(dpred)
         return loss
@@ -1026,7 +1041,7 @@ def l2_loss_and_grad(pred, tgt):
     n = pred_d.numel()
     loss = torch.empty((), device=pred_d.device, dtype=torch.float32)
     dpred = torch.empty_like(pred_d)
-    ws = torch.empty(L.lib().nq_reduce_ws_floats(n), device=pred_d.device, dtype=torch.float32)
+    ws = torch.empty(_q("nq_reduce_ws_floats", n), device=pred_d.device, dtype=torch.float32)
     L.check(L.lib().nq_l2_loss(_p(pred_d), _p(tgt), _p(loss), _p(dpred), _p(ws), n, n // pred_d.shape[1], 1.0, _stream()),
             "l2_loss")
     return loss, dpred
@@ -1061,7 +1076,7 @@ def l2_loss_head_grad(pred, tgt=None, cache_u8=None, idx=None):
     loss = torch.empty((), device=pred_d.device, dtype=torch.float32)
     dconv = torch.empty_like(pred_d)
     db = torch.empty(C, device=pred_d.device, dtype=torch.float32)
-    ws = torch.empty(2 * L.lib().nq_reduce_ws_floats(n), device=pred_d.device, dtype=torch.float32)
+    ws = torch.empty(2 * _q("nq_reduce_ws_floats", n), device=pred_d.device, dtype=torch.float32)
     L.check(L.lib().nq_l2_loss_tanh_head(_p(pred_d), _p(tgt) if cache_u8 is None else None,
                                          _p(cache_u8) if cache_u8 is not None else None,
                                          _p(idx) if cache_u8 is not None else None, _p(loss), _p(dconv), _p(db), _p(ws),
