@@ -135,6 +135,16 @@ int nq_adam_step_multi_dyn(const nq_adam_seg* segs, int nseg, const float* dyn, 
  * length n = 2^k <= 1024, n_in <= n, n_out <= n.  x and y must not alias. */
 int nq_fwht(const float* x, float* y, int64_t outer, int n, int64_t inner, int n_in, int n_out, nq_stream_t stream);
 
+/* nq_fwht for several tensors in ONE launch (all layers of a decoder); `segs` is a host array, the pointers inside are
+ * device pointers; fields as the arguments of nq_fwht (same arithmetic, bit-identical results). */
+typedef struct nq_fwht_seg {
+  const float* x;
+  float* y;
+  int64_t outer, inner;
+  int n, n_in, n_out;
+} nq_fwht_seg;
+int nq_fwht_multi(const nq_fwht_seg* segs, int nseg, nq_stream_t stream);
+
 /* ---------------------------------------------------------------- convolution side ------------ */
 
 /* Re-layout an OIHW weight (Cout,Cin,k,k) into the two GEMM operands the conv kernels read:

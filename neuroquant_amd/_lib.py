@@ -34,6 +34,12 @@ class WLSeg(Structure):
                 ("krows_fwd", c_int), ("ld_fwd", c_int), ("krows_bwd", c_int), ("ld_bwd", c_int)]
 
 
+class FwhtSeg(Structure):
+    """nq_fwht_seg (include/nq_hip.h)."""
+    _fields_ = [("x", c_void_p), ("y", c_void_p), ("outer", c_int64), ("inner", c_int64), ("n", c_int), ("n_in", c_int),
+                ("n_out", c_int)]
+
+
 class AdamSeg(Structure):
     """nq_adam_seg (include/nq_hip.h)."""
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64)]
@@ -71,6 +77,7 @@ def _load():
     sig("nq_round_loss_backward", I, P, L, F, F, P, P, I, P)
     sig("nq_adam_step", I, P, P, P, P, L, F, F, F, F, F, P)
     sig("nq_fwht", I, P, P, L, I, L, I, I, P)
+    sig("nq_fwht_multi", I, POINTER(FwhtSeg), I, P)
     sig("nq_weight_layouts", I, P, P, P, I, I, I, I, I, I, I, P)
     sig("nq_conv_operand_dims", I, I, I, I, POINTER(c_int), POINTER(c_int))
     sig("nq_conv_forward_ws_floats", L, I, I, I, I, I, I)
@@ -101,7 +108,7 @@ def _load():
 EXPORTS = (
     "nq_abi_version", "nq_error_string", "nq_scale_init_max", "nq_uaq_forward", "nq_uaq_backward",
     "nq_adaround_init", "nq_adaround_forward", "nq_adaround_backward", "nq_reduce_ws_floats", "nq_round_loss", "nq_round_loss_backward",
-    "nq_adam_step", "nq_adaround_forward_multi", "nq_adaround_backward_multi", "nq_adam_step_multi", "nq_step_prologue", "nq_adaround_backward_multi_dyn", "nq_adam_step_multi_dyn", "nq_fwht", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
+    "nq_adam_step", "nq_adaround_forward_multi", "nq_adaround_backward_multi", "nq_adam_step_multi", "nq_step_prologue", "nq_adaround_backward_multi_dyn", "nq_adam_step_multi_dyn", "nq_fwht", "nq_fwht_multi", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
     "nq_conv3_supported", "nq_conv3_weight_bytes", "nq_weight_layout3", "nq_weight_layout3_multi", "nq_weight_layouts_multi", "nq_conv_forward3_ws_floats", "nq_conv_forward3",
     "nq_conv_wgrad3_supported", "nq_conv_wgrad3_ws_floats", "nq_conv_wgrad3", "nq_conv_wgrad3_swapped",
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",

@@ -15,11 +15,44 @@ namespace {
 constexpr int TPB = 256;
 constexpr int LDS_FLOATS = 8192 + 1024;
 
-__global__ __launch_bounds__(TPB) void fwht_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t outer,
-                                                   int n, int log2n, int inner, int n_in, int n_out, int OPB,
-                                                   float sqrt_n) {
-  __shared__ float lds[LDS_FLOATS];
-  const int64_t o0 = (int64_t)blockIdx.x * OPB;
+// G butterfly stages s0 .. s0+G-1 in one pass: a thread takes the 2^G rows that differ in bits s0 .. s0+G-1 of one column
+template <int G>
+__device__ __forceinline__ void fwht_pass(float* lds, int n, int s0, int TC, int LD) {
+  constexpr int R = 1 << G;
+  const int groups = (n >> G) * TC, h0 = 1 << s0;
+  for (int e = threadIdx.x; e < groups; e += TPB) {
+    const int q = e / TC, t = e - q * TC;
+    const int base = ((q >> s0) << (s0 + G)) | (q & (h0 - 1));   // row with bits s0 .. s0+G-1 clear
+    float v[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) v[j] = lds[(base + j * h0) * LD + t];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        if ((j & (1 << g)) == 0) {
+          const float a = v[j], b = v[j | (1 << g)];
+          v[j] = a + b;
+          v[j | (1 << g)] = a - b;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) lds[(base + j * h0) * LD + t] = v[j];
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void fwht_stages(float* lds, int n, int log2n, int TC, int LD) {
+  int s = 0;
+  for (; s + 3 <= log2n; s += 3) fwht_pass<3>(lds, n, s, TC, LD);
+  if (log2n - s == 2) fwht_pass<2>(lds, n, s, TC, LD);
+  else if (log2n - s == 1) fwht_pass<1>(lds, n, s, TC, LD);
+}
+
+__device__ __forceinline__ void fwht_block(float* lds, int blk, const float* __restrict__ x, float* __restrict__ y,
+                                           int64_t outer, int n, int log2n, int inner, int n_in, int n_out, int OPB,
+                                           float sqrt_n) {
+  const int64_t o0 = (int64_t)blk * OPB;
   const int nob = (int)min((int64_t)OPB, outer - o0);   // outer rows of this block
   const int TC = OPB * inner, LD = TC + 1;
   // rows [n_in, n): the zero padding
@@ -38,19 +71,10 @@ __global__ __launch_bounds__(TPB) void fwht_kernel(const float* __restrict__ x, 
     }
   }
   __syncthreads();
-  // butterflies
-  const int pairs = (n >> 1) * TC;
-  for (int s = 0; s < log2n; ++s) {
-    const int h = 1 << s;
-    for (int e = threadIdx.x; e < pairs; e += TPB) {
-      int p = e / TC, t = e - p * TC;
-      int c = ((p >> s) << (s + 1)) | (p & (h - 1));  // index with bit s clear
-      float a = lds[c * LD + t], b = lds[(c + h) * LD + t];
-      lds[c * LD + t] = a + b;
-      lds[(c + h) * LD + t] = a - b;
-    }
-    __syncthreads();
-  }
+  // butterflies: up to three stages per pass over LDS (an element's 8 / 4 / 2 partners in registers), each stage the same
+  // (a, b) -> (a + b, a - b) on the same operands as the one-stage-per-pass loop (bit-identical), with a third of the
+  // LDS round trips and barriers
+  fwht_stages(lds, n, log2n, TC, LD);
   // store the first n_out entries: linear sweep over the block's contiguous output
   {
     const int per_o = n_out * inner, total = nob * per_o;
@@ -61,6 +85,35 @@ __global__ __launch_bounds__(TPB) void fwht_kernel(const float* __restrict__ x, 
       yb[e] = lds[c * LD + ol * inner + ii] / sqrt_n;
     }
   }
+}
+
+__global__ __launch_bounds__(TPB) void fwht_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t outer,
+                                                   int n, int log2n, int inner, int n_in, int n_out, int OPB,
+                                                   float sqrt_n) {
+  __shared__ float lds[LDS_FLOATS];
+  fwht_block(lds, (int)blockIdx.x, x, y, outer, n, log2n, inner, n_in, n_out, OPB, sqrt_n);
+}
+
+// several tensors in ONE launch (all layers of a decoder: the per-layer launches are 10 us each for ~1 us of traffic)
+constexpr int FW_MAXSEG = 16;
+struct FwSeg {
+  const float* x;
+  float* y;
+  int64_t outer;
+  int n, log2n, inner, n_in, n_out, OPB;
+  float sqrt_n;
+};
+struct FwMulti {
+  FwSeg s[FW_MAXSEG];
+  int blk0[FW_MAXSEG + 1];
+  int nseg;
+};
+__global__ __launch_bounds__(TPB) void fwht_multi_kernel(FwMulti t) {
+  __shared__ float lds[LDS_FLOATS];
+  int k = 0;
+  while (k + 1 < t.nseg && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
+  const FwSeg& g = t.s[k];
+  fwht_block(lds, (int)blockIdx.x - t.blk0[k], g.x, g.y, g.outer, g.n, g.log2n, g.inner, g.n_in, g.n_out, g.OPB, g.sqrt_n);
 }
 
 // Fallback for rows too long for the tile above (n*inner > 8192): TC arbitrary columns per workgroup, gathered.
@@ -82,19 +135,7 @@ __global__ __launch_bounds__(TPB) void fwht_cols_kernel(const float* __restrict_
     lds[c * LD + t] = v;
   }
   __syncthreads();
-  // butterflies
-  const int pairs = (n >> 1) * TC;
-  for (int s = 0; s < log2n; ++s) {
-    const int h = 1 << s;
-    for (int e = threadIdx.x; e < pairs; e += TPB) {
-      int p = e / TC, t = e - p * TC;
-      int c = ((p >> s) << (s + 1)) | (p & (h - 1));  // index with bit s clear
-      float a = lds[c * LD + t], b = lds[(c + h) * LD + t];
-      lds[c * LD + t] = a + b;
-      lds[(c + h) * LD + t] = a - b;
-    }
-    __syncthreads();
-  }
+  fwht_stages(lds, n, log2n, TC, LD);
   // store first n_out entries
   for (int e = threadIdx.x; e < n_out * TC; e += TPB) {
     int c = e / TC, t = e - c * TC;
@@ -133,5 +174,45 @@ extern "C" int nq_fwht(const float* x, float* y, int64_t outer, int n, int64_t i
   if (blocks > 0x7fffffffLL) return NQ_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(fwht_kernel, dim3((unsigned)blocks), dim3(TPB), 0, nq_s(stream), x, y, outer, n, log2n, (int)inner, n_in,
                      n_out, OPB, sqrtf((float)n));
+  return nq_launch_status();
+}
+
+extern "C" int nq_fwht_multi(const nq_fwht_seg* segs, int nseg, nq_stream_t stream) {
+  if (!segs || nseg <= 0) return NQ_ERR_INVALID;
+  FwMulti t;
+  t.nseg = 0;
+  int blocks = 0;
+  auto flush = [&]() {
+    if (t.nseg == 0) return;
+    t.blk0[t.nseg] = blocks;
+    hipLaunchKernelGGL(fwht_multi_kernel, dim3((unsigned)blocks), dim3(TPB), 0, nq_s(stream), t);
+    t.nseg = 0;
+    blocks = 0;
+  };
+  for (int i = 0; i < nseg; ++i) {
+    const nq_fwht_seg& h = segs[i];
+    if (!h.x || !h.y || h.x == h.y || h.outer <= 0 || h.inner <= 0 || h.n <= 0 || (h.n & (h.n - 1)) != 0) return NQ_ERR_INVALID;
+    if (h.n_in <= 0 || h.n_in > h.n || h.n_out <= 0 || h.n_out > h.n) return NQ_ERR_INVALID;
+    if (h.n > 1024) return NQ_ERR_UNSUPPORTED;
+    if ((int64_t)h.n * h.inner > 8192) {   // long rows: the single-tensor column-gather variant
+      int rc = nq_fwht(h.x, h.y, h.outer, h.n, h.inner, h.n_in, h.n_out, stream);
+      if (rc != NQ_OK) return rc;
+      continue;
+    }
+    int log2n = 0;
+    while ((1 << log2n) < h.n) ++log2n;
+    int OPB = (int)(8192 / ((int64_t)h.n * h.inner));
+    const int cap = (int)((32 + h.inner - 1) / h.inner);
+    if (OPB > cap) OPB = cap;
+    if (OPB < 1) OPB = 1;
+    const int64_t nb = (h.outer + OPB - 1) / OPB;
+    if (nb + blocks > 0x7fffffffLL) return NQ_ERR_UNSUPPORTED;
+    if (t.nseg == FW_MAXSEG) flush();
+    t.s[t.nseg] = FwSeg{h.x, h.y, h.outer, h.n, log2n, (int)h.inner, h.n_in, h.n_out, OPB, sqrtf((float)h.n)};
+    t.blk0[t.nseg] = blocks;
+    blocks += (int)nb;
+    ++t.nseg;
+  }
+  flush();
   return nq_launch_status();
 }

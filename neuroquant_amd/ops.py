@@ -346,6 +346,21 @@ def fwht_channels(w: torch.Tensor, n: int, n_out: int) -> torch.Tensor:
     return y
 
 
+def fwht_channels_multi(items):
+    """items: [(w, n, n_out)] -> [fwht_channels(w, n, n_out)], ONE launch for all tensors (bit-identical results)."""
+    segs = (L.FwhtSeg * len(items))()
+    outs = []
+    for sg, (w, n, n_out) in zip(segs, items):
+        w = _dev(w)
+        co, c, kh, kw = w.shape
+        y = torch.empty((co, n_out, kh, kw), device=w.device, dtype=torch.float32)
+        sg.x, sg.y, sg.outer, sg.inner, sg.n, sg.n_in, sg.n_out = _p(w), _p(y), co, kh * kw, n, c, n_out
+        outs.append(y)
+    if items:
+        L.check(L.lib().nq_fwht_multi(segs, len(items), _stream()), "fwht_multi")
+    return outs
+
+
 class _HadamardFn(Function):
     @staticmethod
     def forward(ctx, w, n, n_out):

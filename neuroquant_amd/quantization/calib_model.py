@@ -111,8 +111,8 @@ class _Layer:
         return [(self.src, wq.alpha.data, wq.delta.data, wq.zero_point, wq.n_levels, wq.soft_targets),
                 (self.bias, bq.alpha.data, bq.delta.data, bq.zero_point, bq.n_levels, bq.soft_targets)]
 
-    def _finish(self, Wq, b):
-        self.W = (ops.fwht_channels(Wq, self.n, self.c_in) if self.hadamard else Wq).requires_grad_(True)
+    def _finish(self, Wq, b, transformed=False):
+        self.W = (ops.fwht_channels(Wq, self.n, self.c_in) if self.hadamard and not transformed else Wq).requires_grad_(True)
         self.b = b.requires_grad_(True)
         self.m._wb_override = (self.W, self.b)
 
@@ -204,8 +204,13 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
             if ada:   # all 14 fake-quantised tensors in one launch
                 fq = ops.adaround_forward_multi(
                     [it for L in layers for it in L.ada_items()])
-                for i, L in enumerate(layers):
-                    L._finish(fq[2 * i], fq[2 * i + 1])
+                if hadamard:   # H(Q(H w)) of every layer in one launch (quant_layer.py:70-71)
+                    had = ops.fwht_channels_multi([(fq[2 * i], L.n, L.c_in) for i, L in enumerate(layers)])
+                    for i, L in enumerate(layers):
+                        L._finish(had[i], fq[2 * i + 1], transformed=True)
+                else:
+                    for i, L in enumerate(layers):
+                        L._finish(fq[2 * i], fq[2 * i + 1])
             else:
                 for L in layers:
                     L.forward_uaq()
@@ -228,8 +233,10 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
             grads = []
             if ada:   # d(alpha) of all 14 tensors (+ regulariser gradient on the weights) in one launch
                 items = []
-                for L in layers:
-                    gW, gb = L.grads()
+                # H on the zero-padded gradients of all layers in one launch
+                gWs = ops.fwht_channels_multi([(L.W.grad, L.n, L.n) for L in layers]) if hadamard else None
+                for i, L in enumerate(layers):
+                    gW, gb = (gWs[i], L.b.grad) if hadamard else L.grads()
                     wq, bq = L.m.weight_quantizer, L.m.bias_quantizer
                     # with dyn the regulariser weight is always passed and gated on the device by dyn[1]
                     items.append((L.src, gW, wq.alpha.data, wq.delta.data, wq.zero_point, wq.n_levels,

@@ -892,6 +892,19 @@ def test_multi_tensor_kernels_equal_single_tensor_ones(ops):
         assert torch.equal(a, b)
 
 
+def test_fwht_multi_equals_single(ops):
+    """nq_fwht_multi (all layers in one launch, > 16 segments = chunked, one long-row tensor on the single-tensor variant)."""
+    g = torch.Generator().manual_seed(6)
+    shapes = [(92, 16, 1, 1), (37, 5, 3, 3), (148, 44, 5, 5), (24, 200, 3, 3), (16, 1024, 3, 3), (64, 64, 1, 1)] * 3
+    items = []
+    for i, shp in enumerate(shapes):
+        w = torch.randn(shp, generator=g).to(DEV)
+        n = ops.next_pow2(shp[1])
+        items.append((w, n, shp[1] if i % 2 else n))
+    for (w, n, n_out), y in zip(items, ops.fwht_channels_multi(items)):
+        assert torch.equal(y, ops.fwht_channels(w, n, n_out))
+
+
 def test_weight_layouts_multi_equals_single(ops):
     """nq_weight_layouts_multi (both fp32 operands of several layers, one launch, > 16 segments = chunked) vs nq_weight_layouts."""
     g = torch.Generator().manual_seed(5)
