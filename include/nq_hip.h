@@ -220,6 +220,10 @@ int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* 
 /* bf16x3 variant of nq_conv_wgrad (same contract, x_gelu not offered): */
 int nq_conv_wgrad3_supported(int B, int Cin, int H, int W, int Cout, int k);
 int64_t nq_conv_wgrad3_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
+/* The launch plan nq_conv_wgrad3 will use for this shape (pure host function): MT = 16*mi channels x NT = 64*ni columns per
+ * workgroup, nsplit K-splits, pc != 0 -> the 8-wave producer/consumer kernel (32-bit buffer offsets: only for operands
+ * below 2 GiB), pc == 0 -> the 4-wave kernel (64-bit pointers). */
+int nq_conv_wgrad3_plan(int B, int Cin, int H, int W, int Cout, int k, int* mi, int* ni, int* nsplit, int* pc);
 int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                    int k, nq_stream_t stream);
 /* The same weight gradient dw (Cout,Cin,k,k) for a convolution with very FEW output channels (the 3-channel head, HNeRV.py:42)

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NQ_LIB") or os.path.join(_HERE, "libnqhip.so")
 
 NQ_OK = 0
+ABI_VERSION = 3   # nq_abi_version() of the library this binding was written against (include/nq_hip.h)
 EPI_PLAIN, EPI_PS_GELU, EPI_TANH, EPI_PS, EPI_DGRAD_GELU = 0, 1, 2, 3, 4
 
 
@@ -59,6 +60,11 @@ def _load():
         fn.argtypes = list(args)
 
     sig("nq_abi_version", I)
+    # a stale / foreign build (NQ_LIB) would be called with shifted arguments: wild device writes instead of an error
+    got = lib.nq_abi_version()
+    if got != ABI_VERSION:
+        raise NQLibraryError(f"{LIB_PATH} has ABI version {got}, this package binds version {ABI_VERSION}: rebuild it "
+                             "(`make -C neuroquant_amd/csrc`)")
     sig("nq_error_string", c_char_p, I)
     sig("nq_scale_init_max", I, P, L, L, I, P, P, P)
     sig("nq_uaq_forward", I, P, P, P, P, L, L, I, I, P)
@@ -91,6 +97,7 @@ def _load():
     sig("nq_conv_forward3", I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P)
     sig("nq_conv_wgrad3_supported", I, I, I, I, I, I, I)
     sig("nq_conv_wgrad3_ws_floats", L, I, I, I, I, I, I)
+    sig("nq_conv_wgrad3_plan", I, I, I, I, I, I, I, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int))
     sig("nq_conv_wgrad3", I, P, P, P, P, P, I, I, I, I, I, I, P)
     sig("nq_conv_wgrad3_swapped", I, P, P, P, P, I, I, I, I, I, I, P)
     sig("nq_conv_wgrad_ws_floats", L, I, I, I, I, I, I)
@@ -110,7 +117,7 @@ EXPORTS = (
     "nq_adaround_init", "nq_adaround_forward", "nq_adaround_backward", "nq_reduce_ws_floats", "nq_round_loss", "nq_round_loss_backward",
     "nq_adam_step", "nq_adaround_forward_multi", "nq_adaround_backward_multi", "nq_adam_step_multi", "nq_step_prologue", "nq_adaround_backward_multi_dyn", "nq_adam_step_multi_dyn", "nq_fwht", "nq_fwht_multi", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
     "nq_conv3_supported", "nq_conv3_weight_bytes", "nq_weight_layout3", "nq_weight_layout3_multi", "nq_weight_layouts_multi", "nq_conv_forward3_ws_floats", "nq_conv_forward3",
-    "nq_conv_wgrad3_supported", "nq_conv_wgrad3_ws_floats", "nq_conv_wgrad3", "nq_conv_wgrad3_swapped",
+    "nq_conv_wgrad3_supported", "nq_conv_wgrad3_ws_floats", "nq_conv_wgrad3_plan", "nq_conv_wgrad3", "nq_conv_wgrad3_swapped",
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",
     "nq_channel_sum", "nq_l2_loss_tanh_head", "nq_frame_sse", "nq_gather_frames_u8",
 )

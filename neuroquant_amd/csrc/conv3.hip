@@ -185,8 +185,11 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
   if (ns < 1) ns = 1;
   p.nsplit = ns;
   p.pc = 0;
+  // the producer/consumer kernel addresses x through SIGNED and dy through unsigned 32-bit byte offsets (raw buffer loads):
+  // operands of 2 GiB and more stay on the 4-wave kernel (64-bit pointers)
+  const bool pc_ok = wgrad3_pc_enabled() && (int64_t)B * Cin * H * W * 4 < (1ll << 31) && (int64_t)B * Cout * H * W * 4 < (1ll << 31);
   // producer/consumer kernel (8 waves, ONE workgroup per CU): wide tiles with a long K loop per workgroup
-  if (wgrad3_pc_enabled() && p.ni >= 5 && p.mi >= 3 && tiles <= 256) {
+  if (pc_ok && p.ni >= 5 && p.mi >= 3 && tiles <= 256) {
     // rows per staged segment: 4 (2) where H divides and every workgroup still gets >= 16 segments; NQ_WGRAD3_SS=1 -> 1
     int sy = 1;
     int ns_pc = 256 / tiles;
@@ -204,7 +207,7 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
   // narrow problems streaming a big tensor (the role-swapped head gradient: 3 x 9 n-values, K = all pixels): the 4-wave
   // kernel runs 18 MFMAs per barrier with one 6 KB segment in flight per workgroup (latency-bound, 2.1 TB/s); the
   // producer/consumer kernel with 128-pixel segments keeps 2 x 24 KB in flight per CU
-  if (wgrad3_pc_enabled() && p.ni == 1 && (p.mi == 2 || p.mi == 3) && tiles == 1 && W % 128 == 0) {
+  if (pc_ok && p.ni == 1 && (p.mi == 2 || p.mi == 3) && tiles == 1 && W % 128 == 0) {
     const int nseg_pc = (W / 128) * H * B;
     if (nseg_pc / 256 >= 8) {
       p.pc = 4;
@@ -346,6 +349,13 @@ int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* 
 int nq_conv_wgrad3_supported(int B, int Cin, int H, int W, int Cout, int k) {
   if (!(k == 3 || k == 5) || B <= 0 || Cin <= 0 || Cout <= 4) return 0;
   return (int64_t)((W + 31) / 32) * H * B >= 128;  // enough 32-pixel segments to split over
+}
+
+int nq_conv_wgrad3_plan(int B, int Cin, int H, int W, int Cout, int k, int* mi, int* ni, int* nsplit, int* pc) {
+  if (!(k == 3 || k == 5) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || !mi || !ni || !nsplit || !pc) return NQ_ERR_INVALID;
+  const Wg3Plan p = plan_wgrad3(B, Cin, H, W, Cout, k);
+  *mi = p.mi; *ni = p.ni; *nsplit = p.nsplit; *pc = p.pc;
+  return NQ_OK;
 }
 
 int64_t nq_conv_wgrad3_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {

@@ -162,9 +162,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const_cast<float*>(a.x), 0, (int)(unsigned)((int64_t)a.B * a.Cin * HW * 4), 0x00020000);
   // byte offset of (this split's channel it_oct*8, row, quad); negative only for the quad that starts in the left halo
   // of the very first row of the tensor: that one is loaded from offset 0 and shifted into place (prologue)
-  const int it_base = (int)((((int64_t)b * a.Cin + (int64_t)c_lo * CC + it_oct * 8) * HW + (int64_t)it_gy * W + it_gx) * 4);
+  // (the sign is taken from the 64-bit value: offsets of tensors between 2 and 4 GiB are valid 32-bit UNSIGNED numbers whose
+  // truncation to int is negative; all later offset arithmetic is unsigned and exact modulo 2^32)
+  const int64_t it_base64 = (((int64_t)b * a.Cin + (int64_t)c_lo * CC + it_oct * 8) * HW + (int64_t)it_gy * W + it_gx) * 4;
+  const unsigned it_base = (unsigned)it_base64;
   const unsigned HWb = (unsigned)(HW * 4);
-  const bool it_neg = it_row && it_base < 0;
+  const bool it_neg = it_row && it_base64 < 0;
   const bool x_edge = (x0 == 0) || (x0 + TW + PAD > W);   // block-uniform: some halo columns are outside the image
   f32x4 pv[8];
   u32x4 wvA[WPT], wvB[WPT];
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     /* channels of this item's octet that exist (0 for a thread without an item / a row outside the image): the   \
        offsets are selected with bit masks, not with ?: -- a conditional here comes back as a branch around the load */ \
     const int nv_ = (NQ_IG3_ABL != 1 && it_row) ? min(max(Cin - ((CH) * CC + it_oct * 8), 0), 8) : 0;  \
-    unsigned o_ = (unsigned)it_base + (unsigned)((CH) * CC + (J)) * HWb;                              \
+    unsigned o_ = it_base + (unsigned)((CH) * CC + (J)) * HWb;                                        \
     if ((J) == 0 && (CH) == 0 && it_neg) o_ = 0u;                                                     \
     if (NQ_IG3_ABL == 7) o_ &= 0x3FFF0u;   /* timing only: every patch load hits a 256 KiB window (L2) */ \
     const unsigned sel_ = (unsigned)(((J) - nv_) >> 31);   /* all ones when J < nv_ */                  \

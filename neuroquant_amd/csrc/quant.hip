@@ -398,7 +398,7 @@ inline bool bad_rows(int64_t rows, int64_t row_len) {
 
 extern "C" {
 
-int nq_abi_version(void) { return 2; }
+int nq_abi_version(void) { return 3; }
 
 const char* nq_error_string(int code) {
   switch (code) {

@@ -76,9 +76,11 @@ def dist_setup():
         return 0, 1, 'cuda'
     import torch.distributed as dist
     rank, local = int(os.environ['RANK']), int(os.environ.get('LOCAL_RANK', '0'))
+    # the HSA runtime reads its environment when it initialises, i.e. at the first GPU call below: the variable that makes
+    # RCCL's cross-process buffer sharing use dmabuf (the only IPC mode this host driver supports) must be set BEFORE it
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(local)
     if not dist.is_initialized():
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=torch.device('cuda', local))
     return rank, world, f'cuda:{local}'
 

@@ -4,10 +4,12 @@ PyTorch is plumbing here: device memory, the current HIP stream and the autograd
 the hot path runs in the hand-written gfx950 kernels; there is NO CPU / eager fallback -- every op raises if
 its tensors are not fp32 HIP tensors or if libnqhip.so is missing.
 """
+import contextlib
 import ctypes
 import functools
 import math
 import os
+import threading
 
 import torch
 from torch.autograd import Function
@@ -769,23 +771,43 @@ def _channels_from_space(g, fh, fw):
 
 
 # Data-parallel hook: when set, the decoder node writes ALL conv weight/bias gradients into one flat arena
-# and calls the hook on it once, at the end of its backward (e.g. an in-place RCCL all-reduce with ReduceOp.AVG): no
-# flatten / un-flatten copies around the collective.  model_reconstruction installs it when torch.distributed is up.
-_GRAD_ARENA_HOOK = None
-GRAD_ARENA_REDUCED = False   # set by the node when the hook ran (the caller then skips its own exchange)
+# and calls the hook on it (e.g. an in-place RCCL all-reduce with ReduceOp.AVG): no flatten / un-flatten copies around the
+# collective.  The hook is per-thread state that every decoder node CAPTURES in its forward (ctx.nq_arena), so the
+# backward -- which PyTorch runs on its own autograd thread -- uses what was installed when the forward ran, two decoders
+# in one process do not see each other's hook, and whether the exchange happened is recorded on the node itself
+# (`img.grad_fn.nq_arena_reduced`), not in a module global.
+_ARENA_TLS = threading.local()
 
 
-_GRAD_ARENA_TWO_PHASE = False
+def _arena_state():
+    return getattr(_ARENA_TLS, "state", (None, False))
 
 
 def set_grad_arena_hook(fn, two_phase=False):
     """fn(arena) is called once per backward with the flat gradient arena.  two_phase=True: the node first runs ALL data
     gradients, then the weight gradients of the deep layers (most of the parameters, little work), calls
     fn(arena[:split], False), runs the weight gradients of the last layers (most of the work, few parameters) and calls
-    fn(arena[split:], True): an asynchronous collective started by the first call overlaps the expensive kernels."""
-    global _GRAD_ARENA_HOOK, _GRAD_ARENA_TWO_PHASE
-    _GRAD_ARENA_HOOK = fn
-    _GRAD_ARENA_TWO_PHASE = bool(two_phase) and fn is not None
+    fn(arena[split:], True): an asynchronous collective started by the first call overlaps the expensive kernels.
+    Applies to decoder nodes whose FORWARD runs on this thread from now on; prefer the `grad_arena_hook` context manager."""
+    _ARENA_TLS.state = (fn, bool(two_phase) and fn is not None)
+
+
+@contextlib.contextmanager
+def grad_arena_hook(fn, two_phase=False):
+    """`with ops.grad_arena_hook(fn, two_phase):` installs the hook for the body and restores the previous one on the way
+    out, exceptions included."""
+    prev = _arena_state()
+    set_grad_arena_hook(fn, two_phase)
+    try:
+        yield
+    finally:
+        _ARENA_TLS.state = prev
+
+
+def arena_reduced(img):
+    """True when the decoder node behind `img` handed its gradient arena to a hook during backward (the caller then
+    skips its own gradient exchange)."""
+    return bool(getattr(getattr(img, "grad_fn", None), "nq_arena_reduced", False))
 
 
 _SIDE_STREAMS = {}
@@ -877,7 +899,10 @@ class _DecoderStackFn(Function):
                 x = _space_from_channels(x, *spec.fc_hw).contiguous()
         ctx.spec, ctx.metas, ctx.n = spec, metas, n
         ctx.save_for_backward(x, *saved_in, *saved_z)
-        _HEAD["img_ptr"], _HEAD["dconv"], _HEAD["db"] = (x.data_ptr() if spec.tanh_out else None), None, None
+        # per-node state (reachable from outside as img.grad_fn.<name>): the data-parallel hook installed on this thread
+        # when the forward ran, whether backward handed the arena to it, and the hand-over slot of the fused loss tail
+        ctx.nq_arena, ctx.nq_arena_reduced = _arena_state(), False
+        ctx.nq_head = _HeadHandoff() if spec.tanh_out else None
         return x
 
     @staticmethod
@@ -888,15 +913,22 @@ class _DecoderStackFn(Function):
         d_emb = None
         g = _dev(g_img, "grad")
         head_db = None
-        if spec.tanh_out and _HEAD["dconv"] is not None and _HEAD["dconv"].data_ptr() == g.data_ptr() \
-                and _HEAD["img_ptr"] == img.data_ptr():
-            dconv, head_db = g, _HEAD["db"]   # l2_loss_head_grad already went through the tanh (and summed the bias gradient)
+        head = ctx.nq_head
+        if head is not None and head.dconv is not None:
+            # l2_loss_head_grad handed over the gradient at the head conv's OUTPUT (tanh backward applied) and the head's
+            # bias gradient.  Anything but that very tensor, unmodified, cannot be continued from: say so loudly.
+            if head.dconv.data_ptr() != g.data_ptr() or g.shape != head.dconv.shape:
+                raise RuntimeError("neuroquant_amd: the gradient returned by ops.l2_loss_head_grad must be passed to "
+                                   "backward() as it is (it already contains the tanh backward of this decoder)")
+            dconv = g
+            # scaled / edited in place since the hand-over: the pre-summed bias gradient no longer matches -> re-sum it
+            head_db = head.db if g._version == head.version else None
+            head.dconv = head.db = None
         elif spec.tanh_out:
             dconv = torch.empty_like(g)
             L.check(L.lib().nq_tanh_out_backward(_p(g), _p(img), _p(dconv), g.numel(), _stream()), "tanh_backward")
         else:
             dconv = g
-        _HEAD["img_ptr"], _HEAD["dconv"], _HEAD["db"] = None, None, None
         grads = [None] * (2 * n)
         # The weight gradients are off the critical path (only the data gradients chain): they run on a second HIP
         # stream so that their workgroups fill the partial last rounds ("tails") of the data-gradient kernels and the
@@ -907,7 +939,8 @@ class _DecoderStackFn(Function):
 
         # one flat arena for all weight/bias gradients when a data-parallel hook is installed (in-place collective)
         arena = views = None
-        if _GRAD_ARENA_HOOK is not None:
+        arena_hook, arena_two_phase = ctx.nq_arena
+        if arena_hook is not None:
             sizes = []
             for l in range(n):
                 k, r, act, cout, cin = metas[l][:5]
@@ -960,8 +993,7 @@ class _DecoderStackFn(Function):
             k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[0]
             return conv_forward_raw(dconv, wbk, dims_b, None, cin, k, EPI_PLAIN, 1)[0]
 
-        global GRAD_ARENA_REDUCED
-        if arena is not None and _GRAD_ARENA_TWO_PHASE and n > 1:
+        if arena is not None and arena_two_phase and n > 1:
             # Data-parallel schedule: the data-gradient chain first, then the weight gradients of the deep layers (most
             # of the parameters, a few per cent of the work) whose part of the arena is handed to the hook at once, then
             # the last layers' weight gradients (>= 80 % of the weight-gradient flops) while that collective is in
@@ -981,12 +1013,12 @@ class _DecoderStackFn(Function):
                 grads[2 * l], grads[2 * l + 1] = wgrad(l, dcs[l])
                 dcs[l] = None
             off = sum(sizes[:2 * split])
-            _GRAD_ARENA_HOOK(arena[:off], False)
+            arena_hook(arena[:off], False)
             for l in range(split, n):
                 grads[2 * l], grads[2 * l + 1] = wgrad(l, dcs[l])
                 dcs[l] = None
-            _GRAD_ARENA_HOOK(arena[off:], True)
-            GRAD_ARENA_REDUCED = True
+            arena_hook(arena[off:], True)
+            ctx.nq_arena_reduced = True
             return (d_emb, None) + tuple(grads)
 
         for l in range(n - 1, -1, -1):
@@ -1010,8 +1042,8 @@ class _DecoderStackFn(Function):
             main.wait_stream(side)
             keep.clear()
         if arena is not None:
-            _GRAD_ARENA_HOOK(arena)
-            GRAD_ARENA_REDUCED = True
+            arena_hook(arena)
+            ctx.nq_arena_reduced = True
         return (d_emb, None) + tuple(grads)
 
 
@@ -1062,20 +1094,24 @@ def l2_loss_and_grad(pred, tgt):
     return loss, dpred
 
 
-# Hand-over of the fused loss tail to the decoder node: (output tensor of the last tanh-headed decoder_stack,
-# its conv-output gradient, its bias gradient).  _DecoderStackFn.forward records the image it returned; l2_loss_head_grad
-# fills the gradients; _DecoderStackFn.backward takes them when the incoming gradient IS that dconv tensor.
-_HEAD = {"img_ptr": None, "dconv": None, "db": None}
+class _HeadHandoff:
+    """Hand-over slot of the fused loss tail, owned by ONE decoder node (ctx.nq_head, reachable as img.grad_fn.nq_head):
+    l2_loss_head_grad fills it with the gradient at the head conv's output and the head's bias gradient, the node's
+    backward takes them when the incoming gradient is that very tensor (`version` = its in-place edit counter at the
+    hand-over: an edited gradient is still continued from, but the bias gradient is summed again)."""
+    __slots__ = ("dconv", "db", "version")
+
+    def __init__(self):
+        self.dconv = self.db = self.version = None
 
 
-def l2_loss_head_grad(pred, tgt=None, cache_u8=None, idx=None):
-    """lp_loss(pred, tgt, p=2) for `pred` = the image a tanh-headed `decoder_stack` just returned, fused with what its
-    backward does first: returns (loss, g) where `pred.backward(g)` continues at the head convolution -- g is the
-    gradient at the head conv's OUTPUT (tanh backward applied) and the head's bias gradient is handed over with it
-    (one pass over the image instead of loss + tanh backward + channel sums; the target can be read straight from the
-    uint8 frame cache).  Returns None when the fused kernel does not apply (the caller then uses l2_loss_and_grad)."""
+def l2_loss_tanh_head_raw(pred, tgt=None, cache_u8=None, idx=None):
+    """One nq_l2_loss_tanh_head launch on an image `pred` = tanh(conv)*0.5+0.5: -> (loss, dconv, db) with lp_loss(pred,
+    tgt, p=2), the gradient at the conv OUTPUT (tanh backward applied) and its per-channel sums (the head's bias
+    gradient); the target is `tgt` or frames `cache_u8[idx]/255` read straight from the uint8 cache.  None when the
+    kernel's tiling does not apply (H*W % 4096 != 0)."""
     pred_d = _dev(pred.detach(), "pred")
-    if _HEAD["img_ptr"] != pred_d.data_ptr() or pred_d.dim() != 4 or os.environ.get("NQ_FUSED_LOSS", "1") == "0":
+    if pred_d.dim() != 4:
         return None
     B, C, H, W = pred_d.shape
     if (H * W) % 4096 != 0 or C > 1024:
@@ -1096,8 +1132,26 @@ def l2_loss_head_grad(pred, tgt=None, cache_u8=None, idx=None):
                                          _p(cache_u8) if cache_u8 is not None else None,
                                          _p(idx) if cache_u8 is not None else None, _p(loss), _p(dconv), _p(db), _p(ws),
                                          B, C, H * W, n // C, 1.0, _stream()), "l2_loss_tanh_head")
-    _HEAD["dconv"], _HEAD["db"] = dconv, db
-    return loss, dconv
+    return loss, dconv, db
+
+
+def l2_loss_head_grad(pred, tgt=None, cache_u8=None, idx=None):
+    """lp_loss(pred, tgt, p=2) for `pred` = the image a tanh-headed `decoder_stack` just returned, fused with what its
+    backward does first: returns (loss, g) where `pred.backward(g)` continues at the head convolution -- g is the
+    gradient at the head conv's OUTPUT (tanh backward applied) and the head's bias gradient is handed over with it
+    (one pass over the image instead of loss + tanh backward + channel sums; the target can be read straight from the
+    uint8 frame cache).  The hand-over lives on pred's own autograd node, so g belongs to THIS decoder call only and
+    must reach backward() as returned.  Returns None when `pred` is not such an image (no graph recorded, another
+    producer) or the fused kernel does not apply; the caller then uses l2_loss_and_grad."""
+    head = getattr(pred.grad_fn, "nq_head", None)     # only the tensor a tanh-headed decoder node returned carries one
+    if not isinstance(head, _HeadHandoff) or os.environ.get("NQ_FUSED_LOSS", "1") == "0":
+        return None
+    out = l2_loss_tanh_head_raw(pred, tgt, cache_u8, idx)
+    if out is None:
+        return None
+    loss, head.dconv, head.db = out
+    head.version = head.dconv._version
+    return loss, head.dconv
 
 
 def frame_psnr(out, gt):

@@ -14,6 +14,7 @@ Autograd only spans the convolution stack; the parameter side is explicit, so no
 host synchronisation per iteration (the reference's decode sync and 500-step float() logging are the only
 syncs it had; the log sync is kept, the decode sync is not).
 """
+import contextlib
 import logging
 import os
 
@@ -156,10 +157,12 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
     dp = torch.distributed.is_available() and torch.distributed.is_initialized() and \
         (torch.distributed.get_world_size() > 1 or bool(os.environ.get("NQ_DP_REHEARSAL")))
 
+    hook_scope = contextlib.nullcontext()
     if dp and device.type == 'cuda':
         # fused decoder node: gradients land in one arena that is all-reduced in place (RCCL, mean over ranks), in two
         # asynchronous pieces: the deep layers' gradients (85 % of the bytes of an HNeRV-3M, ready after a few per cent of
-        # the weight-gradient work) travel while the last layers' weight gradients are computed (ops.set_grad_arena_hook)
+        # the weight-gradient work) travel while the last layers' weight gradients are computed (ops.grad_arena_hook).
+        # The hook is scoped to this call: removed on the way out, exceptions included.
         import torch.distributed as dist
         pending = []
 
@@ -170,7 +173,7 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                     w.wait()
                 pending.clear()
 
-        ops.set_grad_arena_hook(reduce_part, two_phase=os.environ.get("NQ_DP_OVERLAP", "1") != "0")
+        hook_scope = ops.grad_arena_hook(reduce_part, two_phase=os.environ.get("NQ_DP_OVERLAP", "1") != "0")
 
     # Captured iterations (hipGraph): when `gt` can hand over a whole epoch of frame indices
     # (utils.CacheLoader.epoch_indices) the iteration is captured ONCE per phase with torch.cuda.graph and replayed: the
@@ -214,7 +217,6 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
             else:
                 for L in layers:
                     L.forward_uaq()
-            ops.GRAD_ARENA_REDUCED = False
             img_out, _, _ = model(inputs)
             # lp_loss p=2 (quantizer.py:66-71) and its gradient; behind a tanh-headed fused decoder the loss kernel also
             # applies the tanh backward and sums the head's bias gradient (ops.l2_loss_head_grad), reading the target
@@ -227,7 +229,7 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                 fused = ops.l2_loss_and_grad(img_out, img)
             rec, dimg = fused
             img_out.backward(dimg)
-            if dp and not ops.GRAD_ARENA_REDUCED:
+            if dp and not ops.arena_reduced(img_out):
                 # generic path (decoder not fused into one node): flatten, all-reduce, un-flatten
                 allreduce_mean_([t.grad for L in layers for t in (L.W, L.b)])
             grads = []
@@ -328,29 +330,28 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                     opt.t += 1
                 done += 1
 
-    # ---- phase 1: scales (calib_model.py:119-165; lr and max_count are hard-coded there) ----
-    params = []
-    for L in layers:
-        params += [L.m.weight_quantizer.delta, L.m.bias_quantizer.delta]
-    epochs1 = int(0.05 * iters / len(gt))
-    run(epochs1, params, 0.001, 2100, ada=False)
-    torch.cuda.empty_cache()
+    with hook_scope:
+        # ---- phase 1: scales (calib_model.py:119-165; lr and max_count are hard-coded there) ----
+        params = []
+        for L in layers:
+            params += [L.m.weight_quantizer.delta, L.m.bias_quantizer.delta]
+        epochs1 = int(0.05 * iters / len(gt))
+        run(epochs1, params, 0.001, 2100, ada=False)
+        torch.cuda.empty_cache()
 
-    # ---- phase 2: rounding variables (calib_model.py:170-226) ----
-    params = []
-    for L in layers:
-        m = L.m
-        m.weight_quantizer = AdaRoundQuantizer(uaq=m.weight_quantizer, round_mode='learned_hard_sigmoid',
-                                               weight_tensor=(m.hadamard_weight if hadamard else m.org_weight).data)
-        m.bias_quantizer = AdaRoundQuantizer(uaq=m.bias_quantizer, round_mode='learned_hard_sigmoid',
-                                             weight_tensor=m.bias.data)
-        m.weight_quantizer.soft_targets = True
-        m.bias_quantizer.soft_targets = True
-        params += [m.weight_quantizer.alpha, m.bias_quantizer.alpha]
-    run(int(iters / len(gt)) - epochs1, params, lr, iters, ada=True)
-    torch.cuda.empty_cache()
-
-    ops.set_grad_arena_hook(None)
+        # ---- phase 2: rounding variables (calib_model.py:170-226) ----
+        params = []
+        for L in layers:
+            m = L.m
+            m.weight_quantizer = AdaRoundQuantizer(uaq=m.weight_quantizer, round_mode='learned_hard_sigmoid',
+                                                   weight_tensor=(m.hadamard_weight if hadamard else m.org_weight).data)
+            m.bias_quantizer = AdaRoundQuantizer(uaq=m.bias_quantizer, round_mode='learned_hard_sigmoid',
+                                                 weight_tensor=m.bias.data)
+            m.weight_quantizer.soft_targets = True
+            m.bias_quantizer.soft_targets = True
+            params += [m.weight_quantizer.alpha, m.bias_quantizer.alpha]
+        run(int(iters / len(gt)) - epochs1, params, lr, iters, ada=True)
+        torch.cuda.empty_cache()
 
     # ---- finish: weights go hard; the bias quantisers stay soft, as in the reference (calib_model.py:231-240) ----
     for L in layers:

@@ -8,6 +8,12 @@ weights rounded to fp16-representable values so that the fixture is 5 MB instead
 checkpoint (every consumer -- the reference in make_golden.py, the oracle, the HIP engine -- loads the same fp32 numbers).
 
     python3 tests/golden/make_ckpt_fixture.py gpurun_out/hnerv3m_bunny8.pt
+
+Round 3: hnerv3m_bunny8real_f16.npz, the same for the REAL 640x1280 crops (tests/golden/bunny8_640x1280.npz, the first 8
+Bunny frames as the reference's loader crops them) fitted to the reference's operating point (its log: FP 37.57 dB;
+`tools/precision_gate.py --frames bunny_real --train-steps 4000 --save-ckpt gpurun_out/hnerv3m_bunny8real_38.pt`: 38.07 dB):
+
+    python3 tests/golden/make_ckpt_fixture.py gpurun_out/hnerv3m_bunny8real_38.pt hnerv3m_bunny8real_f16.npz
 """
 import os
 import sys
@@ -18,7 +24,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def main(path):
+def main(path, name="hnerv3m_bunny8_f16.npz"):
     blob = torch.load(path, map_location="cpu")
     out = {}
     for k, v in blob["sd"].items():
@@ -27,10 +33,10 @@ def main(path):
         out["sd:" + k.replace(".", "/")] = v.float().half().numpy()      # fp16 storage; consumers cast back to fp32
     out["emb"] = blob["emb"].float().numpy()
     out["fp_psnr_trainer"] = np.array(blob["fp_psnr"])
-    dst = os.path.join(HERE, "hnerv3m_bunny8_f16.npz")
+    dst = os.path.join(HERE, name)
     np.savez_compressed(dst, **out)
     print(f"wrote {dst}: {os.path.getsize(dst) / 1e6:.2f} MB, {len(out)} arrays")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(*sys.argv[1:3])

@@ -19,6 +19,8 @@ Fixtures (what each one pins; reference file:line):
   decode.npz         tiny HNeRV / NeRV decode (FP + quantised), avg bit-width HNeRV.py:49-71, NeRV.py:44-65,
                                                                               quant_model.py:58-72
   frames_320x640.npz 8 Bunny frames, 2x area-downsampled + center-cropped     (data)
+  bunny8_640x1280.npz the first 8 Bunny frames, center-cropped to 640x1280 as the reference's loader does
+                     (data; the operating point of the reference's logged runs)       videosets/datasets.py:19-28
   traj_hnerv.npz     tiny HNeRV: checkpoint, embeddings, batch order, per-iteration losses of the
                      real model_reconstruction, final alpha/delta/x_quant, PSNRs    calib_model.py:92-240
   traj_nerv_had.npz  tiny NeRV + Hadamard: same (FWHT via stub -> "parity unpinned" at the transform)
@@ -388,6 +390,19 @@ def gen_frames():
     return frames
 
 
+def gen_bunny8_real():
+    """bunny8_640x1280.npz: the first 8 Bunny frames exactly as the reference's loader hands them over -- rows 40:680 of
+    the 720x1280 PNGs = center_crop(img, (640, 1280)) (videosets/datasets.py:19-28), uint8, no resampling.
+    Data only: the PNG pixels, cropped."""
+    from PIL import Image
+    frames = []
+    for i in range(1, 9):
+        a = np.asarray(Image.open(f"{REF}/bunny/{i:04d}.png").convert("RGB"))
+        assert a.shape == (720, 1280, 3)
+        frames.append(a[40:680].transpose(2, 0, 1).copy())
+    save("bunny8_640x1280.npz", frames=np.stack(frames), src_index=np.arange(1, 9))
+
+
 def load_frames():
     p = os.path.join(HERE, "frames_320x640.npz")
     if not os.path.exists(p):
@@ -661,6 +676,7 @@ GENS = {
     "quantmodule": gen_quantmodule,
     "decode": gen_decode,
     "frames": gen_frames,
+    "bunny8_real": gen_bunny8_real,
     "traj_hnerv": lambda: gen_traj("traj_hnerv.npz", "hnerv", HNeRV, TINY_HNERV, False, 400, 150, 2e-3, 903),
     "traj_nerv_had": lambda: gen_traj("traj_nerv_had.npz", "nerv", NeRV, TINY_NERV, True, 200, 150, 2e-3, 904),
     "omega": gen_omega,

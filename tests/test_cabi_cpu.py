@@ -20,7 +20,7 @@ def test_header_symbols_exported():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in nq_hip.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert lib.nq_abi_version() == 2
+    assert lib.nq_abi_version() == 3 == _lib.ABI_VERSION
     assert lib.nq_error_string(-1) == b"invalid argument"
 
 
@@ -42,6 +42,27 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     assert kr.value == 56 * 25 and ld.value == 176
     assert lib.nq_conv_wgrad_ws_floats(2, 44, 320, 640, 148, 5) > 0
     assert lib.nq_reduce_ws_floats(4096 * 3 + 1) == 4
+
+
+def test_wgrad3_plan_keeps_big_operands_off_the_32bit_offset_kernel():
+    """The producer/consumer weight-gradient kernel addresses x through signed and dy through unsigned 32-bit byte offsets
+    (raw buffer loads); an operand of 2 GiB or more must take the 4-wave kernel (64-bit pointers) -- ADVICE r2.  Host-only:
+    the plan is a pure function of the shape."""
+    from neuroquant_amd import _lib
+    lib = _lib.lib()
+
+    def plan(B, cin, H, W, cout, k):
+        v = [ctypes.c_int() for _ in range(4)]
+        assert lib.nq_conv_wgrad3_plan(B, cin, H, W, cout, k, *[ctypes.byref(t) for t in v]) == 0
+        return tuple(t.value for t in v)      # (mi, ni, nsplit, pc)
+
+    assert plan(2, 44, 320, 640, 148, 5) == (5, 6, 42, 14)        # dec5 at the bench's size: 8 waves, 4-row segments
+    assert plan(16, 44, 320, 640, 148, 5)[3] == 14                # per-GPU B = 16 (dY 1.94 GB): still below 2 GiB
+    assert plan(18, 44, 320, 640, 148, 5)[3] == 0                 # dY = 18*148*320*640*4 = 2.18 GB
+    assert plan(2, 148, 1600, 1280, 44, 5)[3] == 0                # x  = 2.42 GB
+    assert plan(2, 3, 640, 1280, 37, 3)[3] == 4                   # the role-swapped head problem: 128-pixel segments
+    assert plan(24, 3, 640, 1280, 37, 3)[3] == 0                  # ... with a 2.9 GB "dy" (the 37-channel activation)
+    assert lib.nq_conv_wgrad3_plan(2, 44, 320, 640, 148, 7, *[ctypes.byref(ctypes.c_int()) for _ in range(4)]) == -1
 
 
 def test_ops_refuse_cpu_tensors():

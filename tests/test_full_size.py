@@ -24,18 +24,18 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-def _setup(arch):
+def _setup(arch, B=2):
     import bench
     from neuroquant_amd.utils import synthetic_frames
     model = bench.build_model(workload=arch)
     sd = {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("encoder")}
-    frames_u8 = synthetic_frames(2, 640, 1280, seed=11, device=DEV)
+    frames_u8 = synthetic_frames(B, 640, 1280, seed=11, device=DEV)
     model = model.to(DEV)
     with torch.no_grad():
         if arch == "hnerv":
-            emb = model.encode(frames_u8.float() / 255.0)
+            emb = torch.cat([model.encode(frames_u8[i:i + 2].float() / 255.0) for i in range(0, B, 2)])
         else:
-            emb = model.encode(torch.tensor([0.25, 0.75], device=DEV))
+            emb = model.encode((torch.arange(B, device=DEV).float() + 0.5) / B)
     return model, sd, frames_u8, emb
 
 
@@ -47,7 +47,7 @@ class _OneBatch:
         return 1
 
     def __iter__(self):
-        idx = torch.arange(2, device=DEV)
+        idx = torch.arange(self.n, device=DEV)
         yield {"img": self.frames, "idx": idx, "norm_idx": idx.float() / self.n}
 
 
@@ -74,7 +74,8 @@ def _gpu_step(model, frames, emb, had, precision, phase):
 
         # len(gt) = 1: iters = 20 -> int(0.05*20/1) = 1 phase-1 epoch; iters = 10 -> none (straight into phase 2)
         iters = 20 if phase == "uaq" else 10
-        model_reconstruction(qnn, cali_data=emb, gt=_OneBatch(frames, 2), arch="hnerv" if not had else "nerv", batch_size=2,
+        B = frames.shape[0]
+        model_reconstruction(qnn, cali_data=emb, gt=_OneBatch(frames, B), arch="hnerv" if not had else "nerv", batch_size=B,
                              iters=iters, weight=0.01, hadamard=had, b_range=(20, 2), warmup=0.0, lr=0.003, max_steps=1,
                              probe=probe)
         return got["arena"], got["params"]
@@ -106,7 +107,7 @@ def _cpu_step(sd, arch, fc_hw, frames, emb, had, phase):
                         edge.append(((xi.abs() < 1e-3) | ((xi - qmax).abs() < 1e-3)))
                 got["edge"] = edge
 
-    order = np.array([[[0, 1]]] * 20)
+    order = np.array([[list(range(frames.shape[0]))]] * 20)
     iters = 20 if phase == "uaq" else 10
     O.calibrate(qs, emb.cpu(), frames.cpu(), order, iters, weight=0.01, b_range=(20, 2), warmup=0.0, lr=0.003, max_steps=1,
                 probe=probe)
@@ -125,10 +126,12 @@ def _cmp(name, a, b, tol, mask=None, report=None):
     assert worst <= tol, f"{name}: max |diff| / max|ref| = {worst:.3e} > {tol:.1e}"
 
 
-# (arch, hadamard): BASELINE configs[1] and configs[2]
-@pytest.mark.parametrize("arch,had", [("hnerv", False), ("nerv", True)])
-def test_full_size_single_step_gradients(arch, had):
-    model, sd, frames_u8, emb = _setup(arch)
+# (arch, hadamard, batch): BASELINE configs[1] and configs[2] at the bench's per-GPU batch of 2, and configs[3]'s GLOBAL
+# batch of 16 on one GPU (grid sizes, split plans and 32-bit buffer offsets at 1.9 GB tensors: the dec5 data gradient's
+# input is 16 x 148 x 320 x 640 x 4 B = 1.94 GB, just below the 2 GiB where signed offsets would wrap)
+@pytest.mark.parametrize("arch,had,B", [("hnerv", False, 2), ("nerv", True, 2), ("hnerv", False, 16)])
+def test_full_size_single_step_gradients(arch, had, B):
+    model, sd, frames_u8, emb = _setup(arch, B)
     frames = frames_u8.float() / 255.0
     fc_hw = (model.fc_h, model.fc_w)
     for phase in ("uaq", "ada"):
@@ -152,7 +155,39 @@ def test_full_size_single_step_gradients(arch, had):
                 ptol = 1e-3 if phase == "uaq" else tol
                 _cmp(f"{arch} {phase} {precision} {kind}", g, r, ptol, mask=mask, report=rep)
             worst = max(rep, key=lambda t: t[1])
-            print(f"[{arch} had={had} {phase} {precision}] worst {worst[0]}: {worst[1]:.2e}")
+            print(f"[{arch} had={had} B={B} {phase} {precision}] worst {worst[0]}: {worst[1]:.2e}")
+
+
+def test_conv3_operands_between_2_and_4_gib():
+    """32-bit buffer offsets of the bf16x3 kernels on operands past 2 GiB: `conv_igemm3` takes tensors below
+    4 GiB with UNSIGNED offsets (the sign of the one halo quad in front of the tensor comes from the 64-bit value), the
+    producer/consumer weight gradient is not offered from 2 GiB on (tests/test_cabi_cpu.py) and the 4-wave kernel with
+    64-bit pointers runs instead.  No CPU oracle at this size: the exact-fp32 kernels (64-bit pointers, another tiling)
+    are the reference, bound 1e-4 of the result's largest entry as everywhere else; the comparison covers every output
+    pixel, i.e. also the rows whose input lies beyond the 2 GiB mark."""
+    from neuroquant_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, cin, cout, H, W, k = 1, 20, 8, 5200, 5200, 5           # x: 20 * 5200^2 * 4 B = 2.16 GB; k = 5, 16 + 4 channels (tail chunk)
+    x = torch.empty(B, cin, H, W, device=DEV)
+    for c in range(cin):
+        x[0, c] = torch.randn(H, W, generator=g).to(DEV)
+    assert x.numel() * 4 > 2 ** 31
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(DEV)
+    assert ops.conv3_supported(B, cin, H, W, cout, k)
+    y3 = ops._conv_plain(x, w, precision="bf16x3")
+    y32 = ops._conv_plain(x, w, precision="fp32")
+    scale = float(y32.abs().max())
+    assert float((y3 - y32).abs().max()) <= 1e-4 * scale
+    assert float((y3[:, :, -64:] - y32[:, :, -64:]).abs().max()) <= 1e-4 * scale and float(y3[:, :, -64:].abs().max()) > 0.1 * scale
+    # weight gradient with x beyond 2 GiB: 48 output channels would select the 8-wave kernel for a smaller tensor
+    del y3
+    dy = torch.empty(B, 48, H, W, device=DEV)
+    for c in range(48):
+        dy[0, c] = torch.randn(H, W, generator=g).to(DEV)
+    assert ops.conv_wgrad3_supported(B, cin, H, W, 48, k)
+    dw3 = ops._wgrad_plain(x, dy, k, precision="bf16x3")
+    dw32 = ops._wgrad_plain(x, dy, k, precision="fp32")
+    assert float((dw3 - dw32).abs().max()) <= 1e-4 * float(dw32.abs().max())
 
 
 @pytest.mark.parametrize("prec", ("fp32", "bf16x3"))

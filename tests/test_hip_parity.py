@@ -932,10 +932,9 @@ def test_fused_loss_tail_equals_separate_kernels(ops, u8):
     cache = torch.randint(0, 256, (7, C, H, W), generator=g, dtype=torch.uint8).to(DEV)
     idx = torch.tensor([5, 0, 3], device=DEV)
     tgt = ops.gather_frames_u8(cache, idx)
-    assert ops.l2_loss_head_grad(pred, tgt=tgt) is None          # not the output of a decoder_stack
-    ops._HEAD["img_ptr"] = pred.data_ptr()                        # what _DecoderStackFn.forward records
-    loss, dconv = ops.l2_loss_head_grad(pred, cache_u8=cache, idx=idx) if u8 else ops.l2_loss_head_grad(pred, tgt=tgt)
-    db = ops._HEAD["db"]
+    assert ops.l2_loss_head_grad(pred, tgt=tgt) is None          # not the output of a decoder_stack: no hand-over
+    loss, dconv, db = ops.l2_loss_tanh_head_raw(pred, cache_u8=cache, idx=idx) if u8 \
+        else ops.l2_loss_tanh_head_raw(pred, tgt=tgt)
     rl, dimg = ops.l2_loss_and_grad(pred, tgt)
     rdconv = torch.empty_like(dimg)
     L = ops.L
@@ -947,11 +946,100 @@ def test_fused_loss_tail_equals_separate_kernels(ops, u8):
     conv = torch.atanh((pred.cpu().double() * 2 - 1).clamp(-1 + 1e-12, 1 - 1e-12)).requires_grad_(True)
     lo = O.lp_loss((torch.tanh(conv) * 0.5 + 0.5).float(), tgt.cpu())
     close(loss, lo, rtol=1e-5)
-    ops._HEAD["img_ptr"], ops._HEAD["dconv"], ops._HEAD["db"] = None, None, None
     odd = torch.rand(2, 3, 17, 23, generator=g).to(DEV)          # H*W % 4096 != 0 -> separate kernels
-    ops._HEAD["img_ptr"] = odd.data_ptr()
-    assert ops.l2_loss_head_grad(odd, tgt=torch.rand(2, 3, 17, 23, generator=g).to(DEV)) is None
-    ops._HEAD["img_ptr"] = None
+    assert ops.l2_loss_tanh_head_raw(odd, tgt=torch.rand(2, 3, 17, 23, generator=g).to(DEV)) is None
+
+
+def test_two_interleaved_decoders_keep_their_own_state(ops, golden):
+    """The in-process hand-offs live on the decoder's own autograd node (round 3): the fused loss tail's
+    head gradient / bias gradient (img.grad_fn.nq_head), the data-parallel arena hook captured at forward time
+    (ctx.nq_arena) and the "arena was reduced" flag.  Two decoders interleaved in one process -- forward A, forward B,
+    loss A, loss B, backward B, backward A -- must give the bits of running them one after the other; a hook installed
+    around A's forward only sees A's arena; an in-place edit of the handed-over gradient re-sums the bias gradient; a
+    foreign gradient is refused loudly."""
+    from neuroquant_amd.models import _decode
+    from neuroquant_amd.quantization import QuantModel
+    z = golden("decode.npz")
+    g = torch.Generator().manual_seed(12)
+    cases = {}
+    for arch, had in (("hnerv", False), ("nerv", True)):
+        qnn = QuantModel(_build(arch, state_dict_from_npz(z, f"{arch}_sd:")), hadamard=had,
+                         weight_quant_params=dict(n_bits=8, channel_wise=True))
+        spec, provs = _decode._fused_stack(qnn.model)
+        emb = G(z[f"{arch}_emb"])
+        tgt = torch.rand(emb.shape[0], 3, 320, 640, generator=g).to(DEV)
+        cases[arch] = (spec, provs, emb, tgt)
+
+    def fwd(arch):
+        spec, provs, emb, tgt = cases[arch]
+        ws = [tuple(t.detach().clone().requires_grad_(True) for t in p()) for p in provs]
+        return ops.decoder_stack(emb, spec, ws), ws, tgt
+
+    def loss_of(out, tgt):
+        fused = ops.l2_loss_head_grad(out, tgt=tgt)
+        assert fused is not None, "tanh-headed decoder output, H*W % 4096 == 0: the fused loss tail applies"
+        return fused
+
+    def grads_of(ws):
+        return [t.grad.clone() for pair in ws for t in pair]
+
+    seq = {}
+    for arch in cases:                                   # one after the other
+        out, ws, tgt = fwd(arch)
+        loss, gimg = loss_of(out, tgt)
+        out.backward(gimg)
+        seq[arch] = (loss.clone(), grads_of(ws))
+    outA, wsA, tgtA = fwd("hnerv")                       # interleaved
+    outB, wsB, tgtB = fwd("nerv")
+    assert outA.grad_fn.nq_head is not outB.grad_fn.nq_head
+    lossA, gA = loss_of(outA, tgtA)
+    lossB, gB = loss_of(outB, tgtB)
+    outB.backward(gB)
+    outA.backward(gA)
+    for arch, loss, ws in (("hnerv", lossA, wsA), ("nerv", lossB, wsB)):
+        assert torch.equal(loss, seq[arch][0])
+        for a, b in zip(grads_of(ws), seq[arch][1]):
+            assert torch.equal(a, b)
+
+    # a hook installed around A's forward belongs to A's node only, and is gone afterwards (also after an exception)
+    seen = []
+    with ops.grad_arena_hook(lambda arena: seen.append(arena.numel())):
+        outA, wsA, tgtA = fwd("hnerv")
+    assert ops._arena_state() == (None, False)
+    outB, wsB, tgtB = fwd("nerv")
+    _, gB = loss_of(outB, tgtB)
+    _, gA = loss_of(outA, tgtA)
+    outB.backward(gB)
+    assert seen == [] and not ops.arena_reduced(outB)
+    outA.backward(gA)
+    assert seen == [sum(t.numel() for t in seq["hnerv"][1])] and ops.arena_reduced(outA)
+    for a, b in zip(grads_of(wsA), seq["hnerv"][1]):
+        assert torch.equal(a, b)
+    with pytest.raises(KeyError):
+        with ops.grad_arena_hook(lambda arena: None, two_phase=True):
+            assert ops._arena_state()[1] is True
+            raise KeyError
+    assert ops._arena_state() == (None, False)
+
+    # the handed-over gradient edited IN PLACE (a caller scaling its loss): still continued from, bias gradient re-summed
+    out, ws, tgt = fwd("hnerv")
+    _, gimg = loss_of(out, tgt)
+    gimg.mul_(0.5)
+    out.backward(gimg)
+    for i, (a, b) in enumerate(zip(grads_of(ws), seq["hnerv"][1])):
+        if i == len(seq["hnerv"][1]) - 1:               # head bias: another (fixed-order) sum of the same values
+            close(a, b * 0.5, rtol=2e-5, atol=1e-9)
+        else:
+            assert torch.equal(a, b * 0.5)
+    # any OTHER tensor cannot be continued from (it would need the tanh backward that the hand-over already applied)
+    out, ws, tgt = fwd("hnerv")
+    _, gimg = loss_of(out, tgt)
+    with pytest.raises(RuntimeError, match="l2_loss_head_grad"):
+        out.backward(gimg * 0.5)
+    # no graph recorded -> nothing to hand over to
+    with torch.no_grad():
+        out = ops.decoder_stack(cases["hnerv"][2], cases["hnerv"][0], [tuple(t.detach() for t in p()) for p in cases["hnerv"][1]])
+    assert out.grad_fn is None and ops.l2_loss_head_grad(out, tgt=cases["hnerv"][3]) is None
 
 
 @pytest.mark.parametrize("arch,had", [("hnerv", False), ("nerv", True)])
