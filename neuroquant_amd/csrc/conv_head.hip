@@ -12,12 +12,24 @@
 //  thread per (ci,kh,kw) was measured slower, 0.66-0.80 ms vs 0.56 ms.)
 // Roofline: HBM (8 TB/s spec / 6.3 TB/s achievable); algorithmic bytes = 4*B*H*W*(C_in + C_out) per launch
 // (+ the same again for z in head_dgrad).
+#include <cstdlib>
+#include <type_traits>
+
 #include "nq_common.h"
 
 namespace {
 
 constexpr int MAXCO = 4;
 using f32x2 = __attribute__((ext_vector_type(2))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int I0, int N, class F>
+__device__ __forceinline__ void hf2_rows(F&& f) {
+  if constexpr (I0 < N) {
+    f(std::integral_constant<int, I0>{});
+    hf2_rows<I0 + 1, N>(f);
+  }
+}
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int KS>
@@ -131,6 +143,160 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
         if (x0 + c4 + p < W) yo[p] = o[p];
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------ forward, streaming
+// Round 3.  The LDS-staged kernel above runs at 2.3 TB/s (wait_any 0.64: 4-channel staging rounds between two barriers,
+// nothing in flight while a workgroup computes).  This one has no LDS and no barrier: a WAVE owns a strip of 256 columns
+// (one 16-byte load per lane and (channel, row): 1 KiB per wave-instruction) and slides down R output rows with the
+// 3 x CO x 4 partial sums of the three output rows an input row contributes to in registers, so every activation is
+// fetched from memory ONCE per R + 2 rows (R = 5: 1.4 x the tensor through L2, the halo rows shared with the row blocks
+// above / below, which the XCD-chunked order runs behind the same L2).  The horizontal halo comes from the neighbouring
+// lanes by DPP wave shifts; the two pixels outside the strip are one extra dword load per (channel, row) with two live
+// lanes.  Loads are bounds-checked buffer loads (rows / columns outside the image read as zero, no branch), issued D
+// steps ahead through a register queue; the weights sit in LDS ({co0..co3} per tap, one fill per workgroup) and are read
+// one channel ahead by broadcast 16-byte reads.  Same fp32 fused multiply-adds in the same (ci, kh, kw) order per output as head_fwd_kernel.
+struct HeadFwd2Args {
+  int B, Cin, H, W, ld, strips, rblocks;
+  unsigned x_bytes;
+};
+
+// (the pointers are kernel PARAMETERS with __restrict__: only then does the compiler know that the stores to y cannot
+// change the weights, and keeps their loads on the scalar unit -- as vector loads they shared the vmcnt queue with the
+// activation loads and every use drained it)
+// wt[(ci*9 + tap)*ld + co], zero for co >= CO (nq_weight_layouts)
+template <int R, int D, int NCO, bool TANH>
+__global__ __launch_bounds__(256) void head_fwd2_kernel(const float* __restrict__ x_, const float* __restrict__ wt,
+                                                        const float* __restrict__ bias, float* __restrict__ y_,
+                                                        HeadFwd2Args a) {
+  constexpr int KS = 3, KK = 9;
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the weights, {co0..co3} per (channel, tap), once per workgroup (Cin * 9 * 16 bytes); the only barrier of the kernel
+  extern __shared__ __attribute__((aligned(16))) f32x4 wl[];
+  for (int e = threadIdx.x; e < a.Cin * KK; e += 256) wl[e] = *reinterpret_cast<const f32x4*>(wt + (int64_t)e * a.ld);
+  __syncthreads();
+  const int total = a.B * a.strips * a.rblocks;
+  const int wid = nq_xcd_chunk((int)blockIdx.x, (int)gridDim.x) * 4 + wave;
+  if (wid >= total) return;   // whole wave
+  const int by = wid % a.rblocks, t0 = wid / a.rblocks;
+  const int sx = t0 % a.strips, b = t0 / a.strips;
+  const int H = a.H, W = a.W, Cin = a.Cin;
+  const int y0 = by * R, x0 = sx * 256, gx = x0 + 4 * lane;
+  const unsigned HWb = (unsigned)H * (unsigned)W * 4u, Wb = (unsigned)W * 4u;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x_), 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(y_, 0, (int)((unsigned)a.B * NCO * HWb), 0x00020000);
+  // per-lane column offsets: the quad, and the one pixel outside the strip that lane 0 (left) / lane 63 (right) fetches
+  const unsigned col_q = (gx < W) ? (unsigned)gx * 4u : OOB;
+  const int ex = (lane == 0) ? x0 - 1 : x0 + 256;
+  const unsigned col_e = ((lane == 0 || lane == 63) && ex >= 0 && ex < W) ? (unsigned)ex * 4u : OOB;
+  const unsigned base_b = (unsigned)b * (unsigned)Cin * HWb;
+
+  // queue of loads in flight: linear step t = row * cpad + ci over the R + 2 input rows
+  const int cpad = (Cin + D - 1) / D * D;
+  f32x4 qv[D];
+  float qe[D];
+  int l_ci = 0, l_row = 0;   // (channel, input row relative to y0 - 1) of the NEXT load to issue: wave-uniform
+  auto issue = [&](f32x4& v, float& e) {
+    const int iy = y0 - 1 + l_row;
+    const bool ok = l_ci < Cin && iy >= 0 && iy < H && l_row < R + 2;
+    const unsigned ro = base_b + (unsigned)l_ci * HWb + (unsigned)iy * Wb;
+    const unsigned m = ok ? 0xFFFFFFFFu : 0u;   // bit masks, not ?: on the offsets -- no branch around the loads
+    const unsigned oq = ((ro + col_q) & m) | (OOB & ~m), oe = ((ro + col_e) & m) | (OOB & ~m);
+    v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (col_q == OOB) ? OOB : oq, 0, 0));
+    e = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (col_e == OOB) ? OOB : oe, 0, 0));
+    const int wrap = (l_ci + 1 == cpad) ? 1 : 0;   // scalar selects, no branch
+    l_ci = wrap ? 0 : l_ci + 1;
+    l_row += wrap;
+  };
+#pragma unroll
+  for (int j = 0; j < D; ++j) issue(qv[j], qe[j]);
+
+  f32x2 acc[3][NCO][2];
+#pragma unroll
+  for (int s = 0; s < 3; ++s)
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) acc[s][co][0] = acc[s][co][1] = f32x2{0.f, 0.f};
+
+  float bv[NCO];
+#pragma unroll
+  for (int co = 0; co < NCO; ++co) bv[co] = bias ? bias[co] : 0.f;
+
+  hf2_rows<0, R + 2>([&](auto iyr_c) {
+    constexpr int iyr = decltype(iyr_c)::value;   // input row y0 - 1 + iyr feeds output rows y0 + iyr - kh, kh = 0..2
+    // the weights of one channel: 9 broadcast 16-byte LDS reads {co0..co3} per tap, fetched ONE channel ahead into the
+    // other register set (LDS returns in order: the compiler waits with a counted lgkmcnt, the next set stays in flight)
+    auto load_w = [&](int ci, f32x4 (&w)[KK]) {
+      const f32x4* __restrict__ wr = wl + min(ci, Cin - 1) * KK;
+#pragma unroll
+      for (int kh = 0; kh < KS; ++kh) {
+        if (iyr - kh < 0 || iyr - kh >= R) continue;   // compile-time: only the taps this input row uses
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) w[kh * KS + kw] = wr[kh * KS + kw];
+      }
+    };
+    auto slot = [&](int ci, int j, f32x4 (&w)[KK], f32x4 (&wn)[KK]) {
+      const f32x4 v = qv[j];
+      const float e = qe[j];
+      issue(qv[j], qe[j]);
+      load_w(ci + 1, wn);
+      // halo pixels from the neighbouring lanes; the strip's outer pixels from the edge load
+      float lf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[3]), 0x138, 0xF, 0xF, false));
+      float rt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[0]), 0x130, 0xF, 0xF, false));
+      lf = (lane == 0) ? e : lf;
+      rt = (lane == 63) ? e : rt;
+      const float in[6] = {lf, v[0], v[1], v[2], v[3], rt};
+#pragma unroll
+      for (int kh = 0; kh < KS; ++kh) {
+        const int rel = iyr - kh;               // output row relative to y0
+        if (rel < 0 || rel >= R) continue;      // compile-time after unrolling
+        const int s = rel % 3;
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
+#pragma unroll
+          for (int co = 0; co < NCO; ++co) {
+            const float wv = w[kh * KS + kw][co];
+            const f32x2 w2 = {wv, wv};
+            acc[s][co][0] = __builtin_elementwise_fma(w2, f32x2{in[kw], in[kw + 1]}, acc[s][co][0]);
+            acc[s][co][1] = __builtin_elementwise_fma(w2, f32x2{in[kw + 2], in[kw + 3]}, acc[s][co][1]);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the queue slots in program order: the younger loads stay in flight
+    };
+    f32x4 wA[KK], wB[KK];
+    load_w(0, wA);
+    static_assert(D % 2 == 0, "the two weight register sets alternate per queue slot");
+#pragma unroll 1
+    for (int c0 = 0; c0 < cpad; c0 += D) {
+#pragma unroll
+      for (int j = 0; j < D; j += 2) {
+        slot(c0 + j, j, wA, wB);
+        slot(c0 + j + 1, j + 1, wB, wA);
+      }
+    }
+    // output row y0 + iyr - 2 has now received its three input rows
+    if constexpr (iyr >= 2) {
+      constexpr int rel = iyr - 2, s = rel % 3;
+      const int oy = y0 + rel;
+      // bounds-checked buffer stores at an out-of-range offset for rows / columns outside the image: no branch around a
+      // memory instruction anywhere in the kernel (a divergent branch with stores in it made the compiler fall back to
+      // vmcnt(0) for every later wait, i.e. drain the load queue at every step)
+      const unsigned so = (oy < H && gx < W) ? ((unsigned)b * NCO * (unsigned)H + (unsigned)oy) * Wb + (unsigned)gx * 4u : OOB;
+#pragma unroll
+      for (int co = 0; co < NCO; ++co) {
+        f32x4 o;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          const float v = acc[s][co][p >> 1][p & 1] + bv[co];
+          o[p] = TANH ? tanhf(v) * 0.5f + 0.5f : v;
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), rs_y,
+                                               so == OOB ? OOB : so + (unsigned)co * HWb, 0, 0);
+        acc[s][co][0] = acc[s][co][1] = f32x2{0.f, 0.f};
+      }
+    }
+  });
 }
 
 // ------------------------------------------------------------------------------------------------ data gradient
@@ -285,6 +451,23 @@ int nq_head_supported(int Cout, int k) { return Cout <= MAXCO && (k == 1 || k ==
 
 int nq_head_forward(const float* x, const float* wt, int ld, const float* bias, float* y, int B, int Cin, int H, int W,
                     int Cout, int k, int epi, hipStream_t st) {
+  // 3x3 heads with whole 16-byte quads per row and a tensor below 4 GiB (32-bit buffer offsets): the streaming kernel
+  const char* hv = getenv("NQ_HEAD_FWD");   // NQ_HEAD_FWD=1: the LDS-staged kernel (A/B runs; read per call)
+  const bool v1 = hv && hv[0] == '1';
+  if (k == 3 && Cout == 3 && (W & 3) == 0 && (ld & 3) == 0 && (int64_t)B * Cin * H * W * 4 < 0xFFFFFF00ll && !v1) {
+    constexpr int R = 5, D = 4;
+    HeadFwd2Args a;
+    a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.ld = ld;
+    a.strips = (W + 255) / 256; a.rblocks = (H + R - 1) / R;
+    a.x_bytes = (unsigned)((int64_t)B * Cin * H * W * 4);
+    const int waves = B * a.strips * a.rblocks;
+    dim3 g2((unsigned)((waves + 3) / 4)), blk2(256);
+    const size_t lds = (size_t)Cin * 9 * 16;
+    if (lds > 64 * 1024) return NQ_ERR_UNSUPPORTED;
+    if (epi == NQ_EPI_TANH) hipLaunchKernelGGL((head_fwd2_kernel<R, D, 3, true>), g2, blk2, lds, st, x, wt, bias, y, a);
+    else hipLaunchKernelGGL((head_fwd2_kernel<R, D, 3, false>), g2, blk2, lds, st, x, wt, bias, y, a);
+    return nq_launch_status();
+  }
   const int tiles_x = (W + 63) / 64, tiles = tiles_x * ((H + 15) / 16);
   dim3 g((unsigned)(tiles * B)), blk(256);
   switch (k) {

@@ -29,6 +29,9 @@ def main(src):
     for key, (name, grid) in MAP.items():
         for r in rows:
             if r["kernel"] == name and (grid is None or r["grid"] == grid):
+                if r.get("clock_suspect") or ((r.get("clock_GHz") or 0) > 2.45 and r["dur_us"] >= 300):
+                    raise SystemExit(f"{name}: clock {r.get('clock_GHz')} GHz on a {r['dur_us']} us dispatch -- broken PMC pass, "
+                                     "take it again (profiles/README.md)")
                 rd, wr = r["hbm_read_MB"] * 1e6, (r["hbm_write_MB"] or 0) * 1e6
                 out[key] = dict(bytes=int(rd + wr), read_bytes=int(rd), write_bytes=int(wr), read_factor=2, batch=2,
                                 kernel=name, dur_us=r["dur_us"], mfma_busy=r.get("mfma_busy_frac"), source=src)

@@ -55,11 +55,23 @@ def main():
         clk = sum(c["GRBM_GUI_ACTIVE"]) / n / 8 / dur if c.get("GRBM_GUI_ACTIVE") else None
         row = dict(kernel=name, grid=int(grid), launches=n, dur_us=round(dur / 1e3, 1), hbm_read_MB=round(rd / 1e6, 1),
                    hbm_write_MB=None if wr is None else round(wr / 1e6, 1), clock_GHz=None if clk is None else round(clk, 2))
+        # a clock above the chip's 2.4 GHz maximum on a dispatch long enough for GRBM_GUI_ACTIVE / 8 / duration to mean
+        # something (guide: the quotient reads high below ~0.3 ms) is a broken pass, not a measurement (round 2 committed
+        # one: 3.49 GHz on the dominant kernel); such rows are marked and make_traffic.py refuses them
+        if clk is not None and clk > 2.45 and dur >= 300e3:
+            row["clock_suspect"] = True
         if key in sq:
             s = {k: sum(v) / len(v) for k, v in sq[key].items() if not k.startswith("dur_ns")}
             sdur = sum(sq[key]["dur_ns:SQ_WAVE_CYCLES"]) / len(sq[key]["dur_ns:SQ_WAVE_CYCLES"])
             wc = s.get("SQ_WAVE_CYCLES", 0) or 1
-            cyc = (clk or 2.2) * sdur * 1024  # SIMD-cycles available during the dispatch (256 CUs x 4 SIMDs)
+            # the clock of THIS pass when it was collected with it (round 3: GRBM_GUI_ACTIVE rides along in the SQ pass, so
+            # the busy fraction and its clock come from the same dispatches), else the fetch pass's
+            clk_sq = s["GRBM_GUI_ACTIVE"] / 8 / sdur if s.get("GRBM_GUI_ACTIVE") else clk
+            if clk_sq is not None and clk_sq > 2.45 and sdur >= 300e3:
+                row["clock_suspect"] = True
+            if "GRBM_GUI_ACTIVE" in s:
+                row["clock_GHz_sq_pass"] = round(clk_sq, 2)
+            cyc = (clk_sq or 2.2) * sdur * 1024  # SIMD-cycles available during the dispatch (256 CUs x 4 SIMDs)
             row.update(mfma_busy_frac=round(s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / cyc, 3),
                        wait_any=round(s.get("SQ_WAIT_ANY", 0) / wc, 3), wait_inst=round(s.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
                        active=round(s.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3),

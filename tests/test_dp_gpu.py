@@ -262,11 +262,13 @@ def test_emulated_world2_arena_reduction(golden, rehearsal_env, monkeypatch, ove
     # vs the single-process global batch: same mathematics (mean over 4 frames = mean of two means over 2), another
     # summation order.  Bounds: 1e-4 of each tensor's largest entry on the arena (measured 3e-5 under bf16x3: 2^-17 per
     # product, tests/test_full_size.py uses the same bound); d(delta) 1e-3 (a sum of cancelling terms,
-    # tests/test_full_size.py); d(alpha) 1e-4.  From the second iteration of a phase on the two runs no longer hold the same
-    # parameters bit for bit (Adam turns a last-bit gradient difference into a +-lr step where the gradient is ~0), so
-    # only the first iteration of each phase is held to the tight bound and the later ones to 5e-2.
+    # tests/test_full_size.py); d(alpha) 1e-4.  From the second iteration on the two runs no longer hold the same
+    # parameters bit for bit (Adam turns a last-bit gradient difference into a +-lr step where the gradient is ~0; measured
+    # 6e-4 on the arena of the first phase-2 iteration, after two such steps of delta), so only the very first iteration is
+    # held to the tight bound and the later ones to 5e-2 -- which a regulariser gradient counted twice (or halved, or
+    # averaged with a stale one) would miss by an order of magnitude: it dominates d(alpha) at b = 20.
     for st, phase in enumerate(single["phases"]):
-        first = st in (0, 2)
+        first = st == 0
         for x, y in zip(runs[0]["arena"][st], single["arena"][st]):
             assert rel(x, y) < (1e-4 if first else 5e-2), (st, rel(x, y))
         for x, y in zip(runs[0]["grads"][st], single["grads"][st]):

@@ -950,6 +950,33 @@ def test_fused_loss_tail_equals_separate_kernels(ops, u8):
     assert ops.l2_loss_tanh_head_raw(odd, tgt=torch.rand(2, 3, 17, 23, generator=g).to(DEV)) is None
 
 
+@pytest.mark.parametrize("shape", [(2, 37, 640, 1280), (1, 24, 320, 640), (3, 5, 17, 36), (1, 37, 7, 260), (2, 9, 64, 1028)])
+@pytest.mark.parametrize("epi_tanh", [True, False])
+def test_head_forward_streaming_kernel(ops, shape, epi_tanh, monkeypatch):
+    """head_fwd2 (round 3: register-streaming, one wave per 256-column strip sliding down 5 rows, halo by DPP wave shifts +
+    an edge load, weights in LDS) against float64 and against the LDS-staged kernel it replaces (NQ_HEAD_FWD=1): strips
+    that end inside / outside the image, row blocks cut by the bottom edge, 1..3 frames, 37 / 24 / few channels.  Bound:
+    2e-6 of the output scale (fp32 fused multiply-adds in another order: (kh, ci, kw) instead of (ci, kh, kw))."""
+    B, cin, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(3, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(DEV)
+    b = (torch.randn(3, generator=g) * 0.1).to(DEV)
+    wt, dims, _, _ = ops.weight_layouts(w, False)
+    epi = ops.EPI_TANH if epi_tanh else ops.EPI_PLAIN
+    monkeypatch.setenv("NQ_HEAD_FWD", "1")
+    y_old = ops.conv_forward_raw(x, wt, dims, b, 3, 3, epi, 1)[0]
+    monkeypatch.setenv("NQ_HEAD_FWD", "0")
+    y_new = ops.conv_forward_raw(x, wt, dims, b, 3, 3, epi, 1)[0]
+    ref = F.conv2d(x.double().cpu(), w.double().cpu(), b.double().cpu(), padding=1)
+    if epi_tanh:
+        ref = torch.tanh(ref) * 0.5 + 0.5
+    scale = float(ref.abs().max())
+    assert float((y_new.cpu().double() - ref).abs().max()) <= 2e-6 * scale
+    assert float((y_new - y_old).abs().max()) <= 2e-6 * scale
+    assert torch.equal(y_new, ops.conv_forward_raw(x, wt, dims, b, 3, 3, epi, 1)[0])   # deterministic
+
+
 def test_two_interleaved_decoders_keep_their_own_state(ops, golden):
     """The in-process hand-offs live on the decoder's own autograd node (round 3): the fused loss tail's
     head gradient / bias gradient (img.grad_fn.nq_head), the data-parallel arena hook captured at forward time

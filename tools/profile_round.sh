@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH --s
 export NQ_GRAPH=0
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/fetch -- $BENCH --steps 3 --warmup 1 > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH --steps 3 --warmup 1 > $OUT/write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU \
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE \
   --output-format csv -d $OUT/sq -- $BENCH --steps 3 --warmup 1 > $OUT/sq.log 2>&1
 unset NQ_GRAPH
 cd $R
