@@ -13,6 +13,7 @@
 // Roofline: HBM (8 TB/s spec / 6.3 TB/s achievable); algorithmic bytes = 4*B*H*W*(C_in + C_out) per launch
 // (+ the same again for z in head_dgrad).
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "nq_common.h"
@@ -146,36 +147,35 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------ forward, streaming
-// Round 3.  The LDS-staged kernel above runs at 2.3 TB/s (wait_any 0.64: 4-channel staging rounds between two barriers,
-// nothing in flight while a workgroup computes).  This one has no LDS and no barrier: a WAVE owns a strip of 256 columns
-// (one 16-byte load per lane and (channel, row): 1 KiB per wave-instruction) and slides down R output rows with the
-// 3 x CO x 4 partial sums of the three output rows an input row contributes to in registers, so every activation is
-// fetched from memory ONCE per R + 2 rows (R = 5: 1.4 x the tensor through L2, the halo rows shared with the row blocks
-// above / below, which the XCD-chunked order runs behind the same L2).  The horizontal halo comes from the neighbouring
-// lanes by DPP wave shifts; the two pixels outside the strip are one extra dword load per (channel, row) with two live
-// lanes.  Loads are bounds-checked buffer loads (rows / columns outside the image read as zero, no branch), issued D
-// steps ahead through a register queue; the weights sit in LDS ({co0..co3} per tap, one fill per workgroup) and are read
-// one channel ahead by broadcast 16-byte reads.  Same fp32 fused multiply-adds in the same (ci, kh, kw) order per output as head_fwd_kernel.
+// Round 3.  The LDS-staged kernel above runs at 2.3-2.5 TB/s (wait_any 0.64: 4-channel staging rounds between two
+// barriers, nothing in flight while a workgroup computes).  This one has no barrier in its loop: a WAVE owns a strip of
+// 256 columns x R output rows and walks the input channels ONCE; per channel it loads the R + 2 input rows (one 16-byte
+// load per lane and row: 1 KiB per wave-instruction, bounds-checked buffer loads at per-row offsets computed once per
+// wave -- rows / columns outside the image read as zero, no branch, no address arithmetic in the loop) one channel ahead
+// into the other register set, and keeps the R x CO x 4 partial sums of all its output rows in registers, so every
+// activation is fetched once per R + 2 rows (R = 5: 1.4 x the tensor through L2; the halo rows are shared with the row
+// blocks above / below, which the XCD-chunked order runs behind the same L2).  The horizontal halo comes from the
+// neighbouring lanes by DPP wave shifts whose "old" operand is the one dword per row that lane 0 / lane 63 fetch from
+// outside the strip.  The weights are wave-uniform: 9 scalar 16-byte loads {co0..co3} per channel, one channel ahead,
+// used as the SGPR operand of v_pk_fma_f32.  A first version (input rows outermost, three accumulator rows, a load queue) was
+// bound by instruction ISSUE at ~1.25 waves per SIMD: 66 bookkeeping instructions per 54 v_pk_fma; this order has ~13.
+// Per output the fp32 fused multiply-adds run in (ci, kh, kw) order, as in head_fwd_kernel.
 struct HeadFwd2Args {
   int B, Cin, H, W, ld, strips, rblocks;
   unsigned x_bytes;
 };
 
-// (the pointers are kernel PARAMETERS with __restrict__: only then does the compiler know that the stores to y cannot
-// change the weights, and keeps their loads on the scalar unit -- as vector loads they shared the vmcnt queue with the
-// activation loads and every use drained it)
+// (the pointers are kernel PARAMETERS with __restrict__: the compiler then knows that the stores to y cannot change x / wt)
 // wt[(ci*9 + tap)*ld + co], zero for co >= CO (nq_weight_layouts)
-template <int R, int D, int NCO, bool TANH>
+template <int R, int NCO, bool TANH>
 __global__ __launch_bounds__(256) void head_fwd2_kernel(const float* __restrict__ x_, const float* __restrict__ wt,
                                                         const float* __restrict__ bias, float* __restrict__ y_,
                                                         HeadFwd2Args a) {
-  constexpr int KS = 3, KK = 9;
+  constexpr int KS = 3, KK = 9, NR = R + 2;
   constexpr unsigned OOB = 0xFFFFFF00u;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the weights, {co0..co3} per (channel, tap), once per workgroup (Cin * 9 * 16 bytes); the only barrier of the kernel
-  extern __shared__ __attribute__((aligned(16))) f32x4 wl[];
-  for (int e = threadIdx.x; e < a.Cin * KK; e += 256) wl[e] = *reinterpret_cast<const f32x4*>(wt + (int64_t)e * a.ld);
-  __syncthreads();
+  // (the wave index through readfirstlane: everything derived from it -- frame, strip, row block, the scalar offsets of the
+  // loads -- is then wave-uniform for the compiler too; as a function of threadIdx it put every load into a waterfall loop)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int total = a.B * a.strips * a.rblocks;
   const int wid = nq_xcd_chunk((int)blockIdx.x, (int)gridDim.x) * 4 + wave;
   if (wid >= total) return;   // whole wave
@@ -186,117 +186,119 @@ __global__ __launch_bounds__(256) void head_fwd2_kernel(const float* __restrict_
   const unsigned HWb = (unsigned)H * (unsigned)W * 4u, Wb = (unsigned)W * 4u;
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x_), 0, (int)a.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(y_, 0, (int)((unsigned)a.B * NCO * HWb), 0x00020000);
-  // per-lane column offsets: the quad, and the one pixel outside the strip that lane 0 (left) / lane 63 (right) fetches
-  const unsigned col_q = (gx < W) ? (unsigned)gx * 4u : OOB;
+  // per-lane byte offsets of the quad and of the one pixel outside the strip (lane 0: left, lane 63: right) in each of the
+  // NR input rows, relative to (frame b, channel 0); out-of-range where the row / column does not exist
   const int ex = (lane == 0) ? x0 - 1 : x0 + 256;
-  const unsigned col_e = ((lane == 0 || lane == 63) && ex >= 0 && ex < W) ? (unsigned)ex * 4u : OOB;
+  const bool e_ok = (lane == 0 || lane == 63) && ex >= 0 && ex < W;
+  unsigned oq[NR], oe[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const int iy = y0 - 1 + r;
+    const bool rok = iy >= 0 && iy < H;
+    oq[r] = (rok && gx < W) ? (unsigned)iy * Wb + (unsigned)gx * 4u : OOB;
+    oe[r] = (rok && e_ok) ? (unsigned)iy * Wb + (unsigned)ex * 4u : OOB;
+  }
   const unsigned base_b = (unsigned)b * (unsigned)Cin * HWb;
 
-  // queue of loads in flight: linear step t = row * cpad + ci over the R + 2 input rows
-  const int cpad = (Cin + D - 1) / D * D;
-  f32x4 qv[D];
-  float qe[D];
-  int l_ci = 0, l_row = 0;   // (channel, input row relative to y0 - 1) of the NEXT load to issue: wave-uniform
-  auto issue = [&](f32x4& v, float& e) {
-    const int iy = y0 - 1 + l_row;
-    const bool ok = l_ci < Cin && iy >= 0 && iy < H && l_row < R + 2;
-    const unsigned ro = base_b + (unsigned)l_ci * HWb + (unsigned)iy * Wb;
-    const unsigned m = ok ? 0xFFFFFFFFu : 0u;   // bit masks, not ?: on the offsets -- no branch around the loads
-    const unsigned oq = ((ro + col_q) & m) | (OOB & ~m), oe = ((ro + col_e) & m) | (OOB & ~m);
-    v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (col_q == OOB) ? OOB : oq, 0, 0));
-    e = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (col_e == OOB) ? OOB : oe, 0, 0));
-    const int wrap = (l_ci + 1 == cpad) ? 1 : 0;   // scalar selects, no branch
-    l_ci = wrap ? 0 : l_ci + 1;
-    l_row += wrap;
+  auto load_x = [&](int ci, f32x4 (&v)[NR], float (&e)[NR]) {
+    const unsigned so = base_b + (unsigned)min(ci, Cin - 1) * HWb;   // scalar offset of the channel (past the end: the last again)
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      v[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, oq[r], so, 0));
+      e[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, oe[r], so, 0));
+    }
   };
+  // the 9 x {co0..co3} weights of a channel: wave-uniform 16-byte loads = scalar loads into SGPRs (v_pk_fma_f32 takes the
+  // pair as its scalar operand: no vector registers, no LDS)
+  const int ld = a.ld;
+  auto load_w = [&](int ci, float4 (&w)[KK]) {
+    const float* __restrict__ wr = wt + (int64_t)min(ci, Cin - 1) * KK * ld;
 #pragma unroll
-  for (int j = 0; j < D; ++j) issue(qv[j], qe[j]);
+    for (int t = 0; t < KK; ++t) w[t] = *reinterpret_cast<const float4*>(wr + t * ld);
+  };
 
-  f32x2 acc[3][NCO][2];
+  f32x2 acc[R][NCO][2];
 #pragma unroll
-  for (int s = 0; s < 3; ++s)
+  for (int r = 0; r < R; ++r)
 #pragma unroll
-    for (int co = 0; co < NCO; ++co) acc[s][co][0] = acc[s][co][1] = f32x2{0.f, 0.f};
+    for (int co = 0; co < NCO; ++co) acc[r][co][0] = acc[r][co][1] = f32x2{0.f, 0.f};
 
-  float bv[NCO];
+  auto compute = [&](const f32x4 (&v)[NR], const float (&e)[NR], const float4 (&w)[KK]) {
 #pragma unroll
-  for (int co = 0; co < NCO; ++co) bv[co] = bias ? bias[co] : 0.f;
-
-  hf2_rows<0, R + 2>([&](auto iyr_c) {
-    constexpr int iyr = decltype(iyr_c)::value;   // input row y0 - 1 + iyr feeds output rows y0 + iyr - kh, kh = 0..2
-    // the weights of one channel: 9 broadcast 16-byte LDS reads {co0..co3} per tap, fetched ONE channel ahead into the
-    // other register set (LDS returns in order: the compiler waits with a counted lgkmcnt, the next set stays in flight)
-    auto load_w = [&](int ci, f32x4 (&w)[KK]) {
-      const f32x4* __restrict__ wr = wl + min(ci, Cin - 1) * KK;
+    for (int r = 0; r < NR; ++r) {   // input row y0 - 1 + r feeds output rows r - kh, kh = 0..2
+      // halo pixels from the neighbouring lanes; lane 0 / lane 63 have no neighbour and keep `old` = the edge dword.
+      // (NB: __builtin_bit_cast applied DIRECTLY to a vector element, `__builtin_bit_cast(int, v[3])`, reads element 0 with
+      // hipcc 7.2 -- checked on a four-line kernel; the elements go through named floats first)
+      const float v3f = v[r][3], v0f = v[r][0], ef = e[r];
+      const int ei = __builtin_bit_cast(int, ef);
+      const float lf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ei, __builtin_bit_cast(int, v3f), 0x138, 0xF, 0xF, false));
+      const float rt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ei, __builtin_bit_cast(int, v0f), 0x130, 0xF, 0xF, false));
+      const float in[6] = {lf, v[r][0], v[r][1], v[r][2], v[r][3], rt};
 #pragma unroll
       for (int kh = 0; kh < KS; ++kh) {
-        if (iyr - kh < 0 || iyr - kh >= R) continue;   // compile-time: only the taps this input row uses
-#pragma unroll
-        for (int kw = 0; kw < KS; ++kw) w[kh * KS + kw] = wr[kh * KS + kw];
-      }
-    };
-    auto slot = [&](int ci, int j, f32x4 (&w)[KK], f32x4 (&wn)[KK]) {
-      const f32x4 v = qv[j];
-      const float e = qe[j];
-      issue(qv[j], qe[j]);
-      load_w(ci + 1, wn);
-      // halo pixels from the neighbouring lanes; the strip's outer pixels from the edge load
-      float lf = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[3]), 0x138, 0xF, 0xF, false));
-      float rt = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[0]), 0x130, 0xF, 0xF, false));
-      lf = (lane == 0) ? e : lf;
-      rt = (lane == 63) ? e : rt;
-      const float in[6] = {lf, v[0], v[1], v[2], v[3], rt};
-#pragma unroll
-      for (int kh = 0; kh < KS; ++kh) {
-        const int rel = iyr - kh;               // output row relative to y0
-        if (rel < 0 || rel >= R) continue;      // compile-time after unrolling
-        const int s = rel % 3;
+        const int rel = r - kh;               // output row relative to y0
+        if (rel < 0 || rel >= R) continue;    // compile-time after unrolling
 #pragma unroll
         for (int kw = 0; kw < KS; ++kw) {
 #pragma unroll
           for (int co = 0; co < NCO; ++co) {
-            const float wv = w[kh * KS + kw][co];
+            const float4 w4 = w[kh * KS + kw];
+            const float wv = co == 0 ? w4.x : (co == 1 ? w4.y : (co == 2 ? w4.z : w4.w));
             const f32x2 w2 = {wv, wv};
-            acc[s][co][0] = __builtin_elementwise_fma(w2, f32x2{in[kw], in[kw + 1]}, acc[s][co][0]);
-            acc[s][co][1] = __builtin_elementwise_fma(w2, f32x2{in[kw + 2], in[kw + 3]}, acc[s][co][1]);
+            acc[rel][co][0] = __builtin_elementwise_fma(w2, f32x2{in[kw], in[kw + 1]}, acc[rel][co][0]);
+            acc[rel][co][1] = __builtin_elementwise_fma(w2, f32x2{in[kw + 2], in[kw + 3]}, acc[rel][co][1]);
           }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);   // keep the queue slots in program order: the younger loads stay in flight
-    };
-    f32x4 wA[KK], wB[KK];
-    load_w(0, wA);
-    static_assert(D % 2 == 0, "the two weight register sets alternate per queue slot");
+    }
+  };
+
+  // two register sets: while channel ci is consumed from one, the loads of channel ci + 1 (14 per wave: 7 KiB) fill the
+  // other; same for the weights in SGPRs.  Scalar loads return out of order, so a wait for them is always "all of them":
+  // it is placed at the END of each compute block, where the next channel's weights (requested a whole block earlier) have
+  // long arrived, instead of in front of the first use, where it would also wait for the requests just issued.
+  f32x4 vA[NR], vB[NR];
+  float eA[NR], eB[NR];
+  float4 wA[KK], wB[KK];
+  load_x(0, vA, eA);
+  load_w(0, wA);
 #pragma unroll 1
-    for (int c0 = 0; c0 < cpad; c0 += D) {
+  for (int ci = 0; ci + 1 < Cin; ci += 2) {
+    load_x(ci + 1, vB, eB);
+    load_w(ci + 1, wB);
+    __builtin_amdgcn_sched_barrier(0);   // the prefetch is issued HERE, not sunk towards its uses one channel later
+    compute(vA, eA, wA);
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_sched_barrier(0);
+    load_x(ci + 2, vA, eA);              // (past the last channel: the last one again, not used)
+    load_w(ci + 2, wA);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(vB, eB, wB);
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (Cin & 1) compute(vA, eA, wA);      // set A holds the last channel
+
+  float bv[NCO];
 #pragma unroll
-      for (int j = 0; j < D; j += 2) {
-        slot(c0 + j, j, wA, wB);
-        slot(c0 + j + 1, j + 1, wB, wA);
+  for (int co = 0; co < NCO; ++co) bv[co] = bias ? bias[co] : 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int oy = y0 + r;
+    // bounds-checked buffer stores (an out-of-range offset for rows / columns outside the image): no branch
+    const unsigned so = (oy < H && gx < W) ? ((unsigned)b * NCO * (unsigned)H + (unsigned)oy) * Wb + (unsigned)gx * 4u : OOB;
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) {
+      f32x4 o;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float v = acc[r][co][p >> 1][p & 1] + bv[co];
+        o[p] = TANH ? tanhf(v) * 0.5f + 0.5f : v;
       }
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), rs_y,
+                                             so == OOB ? OOB : so + (unsigned)co * HWb, 0, 0);
     }
-    // output row y0 + iyr - 2 has now received its three input rows
-    if constexpr (iyr >= 2) {
-      constexpr int rel = iyr - 2, s = rel % 3;
-      const int oy = y0 + rel;
-      // bounds-checked buffer stores at an out-of-range offset for rows / columns outside the image: no branch around a
-      // memory instruction anywhere in the kernel (a divergent branch with stores in it made the compiler fall back to
-      // vmcnt(0) for every later wait, i.e. drain the load queue at every step)
-      const unsigned so = (oy < H && gx < W) ? ((unsigned)b * NCO * (unsigned)H + (unsigned)oy) * Wb + (unsigned)gx * 4u : OOB;
-#pragma unroll
-      for (int co = 0; co < NCO; ++co) {
-        f32x4 o;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          const float v = acc[s][co][p >> 1][p & 1] + bv[co];
-          o[p] = TANH ? tanhf(v) * 0.5f + 0.5f : v;
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), rs_y,
-                                               so == OOB ? OOB : so + (unsigned)co * HWb, 0, 0);
-        acc[s][co][0] = acc[s][co][1] = f32x2{0.f, 0.f};
-      }
-    }
-  });
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ data gradient
@@ -442,6 +444,149 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS <= 3 &&
   }
 }
 
+// ------------------------------------------------------------------------------------------------ data gradient, streaming
+// Round 3, same idea as head_fwd2: a WAVE owns a strip of 256 columns x R rows, no barrier in the loop.  The 3-channel dY
+// neighbourhood of the whole block ((R + 2) rows x CO x (4 + 2) columns; halo by DPP wave shifts, the strip's outer columns
+// by one dword per row and channel) is loaded ONCE into registers; the loop then walks the C_in output channels: 27 x 4
+// fused multiply-adds per row from the register neighbourhood (weights: [ci][co*9 + tap] in LDS, filled once per
+// workgroup, read one channel ahead by 7 broadcast 16-byte reads), times gelu'(z) -- one 16-byte load per row, one channel
+// ahead through bounds-checked buffer loads at per-row offsets computed once -- and two 8-byte PixelUnshuffle(2) stores
+// per row (even / odd pixels; 512 contiguous bytes per wave-instruction).  Per output the fp32 fused multiply-adds run
+// in (co, kh, kw) order, as in head_dgrad_kernel.
+struct HeadDg2Args {
+  int B, Cin, H, W, ld, strips, rblocks;   // Cin = channels of the OUTPUT (naming of head_dgrad_kernel)
+  unsigned dy_bytes, z_bytes;
+};
+
+template <int R, int NCO>
+__global__ __launch_bounds__(256) void head_dgrad2_kernel(const float* __restrict__ dy_, const float* __restrict__ wt,
+                                                          const float* __restrict__ z_, float* __restrict__ out_,
+                                                          HeadDg2Args a) {
+  constexpr int KS = 3, KK = 9, NR = R + 2, WROW = 28;   // 27 weights per output channel, padded to 7 x 16 bytes
+  constexpr unsigned OOB = 0xFFFFFF00u;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int H = a.H, W = a.W, Cin = a.Cin;
+  // wl[ci][co*9 + tap] = wt[(co*9 + tap)*ld + ci]   (wt_bwd operand: k-major, already tap-flipped); the only barrier
+  extern __shared__ __attribute__((aligned(16))) float wl_f[];
+  for (int e = threadIdx.x; e < Cin * WROW; e += 256) {
+    const int ci = e / WROW, j = e - ci * WROW;
+    wl_f[e] = (j < NCO * KK) ? wt[(int64_t)j * a.ld + ci] : 0.f;
+  }
+  __syncthreads();
+  const int total = a.B * a.strips * a.rblocks;
+  const int wid = nq_xcd_chunk((int)blockIdx.x, (int)gridDim.x) * 4 + wave;
+  if (wid >= total) return;   // whole wave
+  const int by = wid % a.rblocks, t0 = wid / a.rblocks;
+  const int sx = t0 % a.strips, b = t0 / a.strips;
+  const int y0 = by * R, x0 = sx * 256, gx = x0 + 4 * lane;
+  const unsigned HWb = (unsigned)H * (unsigned)W * 4u, Wb = (unsigned)W * 4u;
+  const __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy_), 0, (int)a.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_z = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(z_), 0, (int)a.z_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(out_, 0, (int)a.z_bytes, 0x00020000);
+
+  // ---- the dY neighbourhood: nb[row][co] = {left, 4 pixels, right}
+  float nb[NR][NCO][6];
+  {
+    const int ex = (lane == 0) ? x0 - 1 : x0 + 256;
+    const bool e_ok = (lane == 0 || lane == 63) && ex >= 0 && ex < W;
+    f32x4 q[NR][NCO];
+    float ed[NR][NCO];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int iy = y0 - 1 + r;
+      const bool rok = iy >= 0 && iy < H;
+#pragma unroll
+      for (int co = 0; co < NCO; ++co) {
+        const unsigned ro = ((unsigned)(b * NCO + co) * (unsigned)H + (unsigned)iy) * Wb;
+        q[r][co] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_dy, (rok && gx < W) ? ro + (unsigned)gx * 4u : OOB, 0, 0));
+        ed[r][co] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_dy, (rok && e_ok) ? ro + (unsigned)ex * 4u : OOB, 0, 0));
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int co = 0; co < NCO; ++co) {
+        // (named floats: __builtin_bit_cast applied directly to a vector element reads element 0 with hipcc 7.2)
+        const float v3f = q[r][co][3], v0f = q[r][co][0], ef = ed[r][co];
+        const int ei = __builtin_bit_cast(int, ef);
+        nb[r][co][0] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ei, __builtin_bit_cast(int, v3f), 0x138, 0xF, 0xF, false));
+        nb[r][co][5] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(ei, __builtin_bit_cast(int, v0f), 0x130, 0xF, 0xF, false));
+#pragma unroll
+        for (int p = 0; p < 4; ++p) nb[r][co][1 + p] = q[r][co][p];
+      }
+  }
+
+  // per-row byte offsets (relative to (frame b, channel ci)) of the gelu' quad and of the two un-shuffled 8-byte stores:
+  // output row y0 + r, channel ci -> planes ci*4 + (y%2)*2 + {0: even pixels, 1: odd pixels} at (y/2, x/2); the plane of
+  // channel ci*4 starts at the same offset as channel ci of the full-resolution tensor ((b*Cin + ci)*H*W)
+  const unsigned Ho = (unsigned)H >> 1, Wo = (unsigned)W >> 1;
+  unsigned oz[R], oo[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int gy = y0 + r;
+    const bool ok = gy < H && gx < W;
+    oz[r] = ok ? (unsigned)gy * Wb + (unsigned)gx * 4u : OOB;
+    oo[r] = ok ? ((((unsigned)gy & 1u) * 2u * Ho + ((unsigned)gy >> 1)) * Wo + ((unsigned)gx >> 1)) * 4u : OOB;
+  }
+  const unsigned plane_b = Ho * Wo * 4u;
+  const unsigned base_b = (unsigned)b * (unsigned)Cin * HWb;
+
+  auto load_z = [&](int ci, f32x4 (&z)[R]) {
+    const unsigned so = base_b + (unsigned)min(ci, Cin - 1) * HWb;
+#pragma unroll
+    for (int r = 0; r < R; ++r) z[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_z, oz[r], so, 0));
+  };
+  auto load_w = [&](int ci, f32x4 (&w)[WROW / 4]) {
+    const f32x4* __restrict__ wr = reinterpret_cast<const f32x4*>(wl_f) + min(ci, Cin - 1) * (WROW / 4);
+#pragma unroll
+    for (int t = 0; t < WROW / 4; ++t) w[t] = wr[t];
+  };
+  auto compute = [&](int ci, const f32x4 (&z)[R], const f32x4 (&w)[WROW / 4]) {
+    const unsigned so = base_b + (unsigned)ci * HWb;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      f32x2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};   // pixels (0,1) and (2,3)
+#pragma unroll
+      for (int co = 0; co < NCO; ++co)
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < KS; ++kw) {
+            const int j = co * KK + kh * KS + kw;
+            const float wv = w[j >> 2][j & 3];
+            const f32x2 w2 = {wv, wv};
+            const float* in = nb[r + kh][co];
+            acc0 = __builtin_elementwise_fma(w2, f32x2{in[kw], in[kw + 1]}, acc0);
+            acc1 = __builtin_elementwise_fma(w2, f32x2{in[kw + 2], in[kw + 3]}, acc1);
+          }
+      const f32x4 zz = z[r];
+      const f32x2 ev = {acc0[0] * zz[0], acc1[0] * zz[2]}, od = {acc0[1] * zz[1], acc1[1] * zz[3]};
+      const unsigned vo = oo[r];
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, ev), rs_o, vo, so, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, od), rs_o,
+                                            vo == OOB ? OOB : vo + plane_b, so, 0);
+    }
+  };
+
+  f32x4 zA[R], zB[R], wA[WROW / 4], wB[WROW / 4];
+  load_z(0, zA);
+  load_w(0, wA);
+#pragma unroll 1
+  for (int ci = 0; ci + 1 < Cin; ci += 2) {
+    load_z(ci + 1, zB);
+    load_w(ci + 1, wB);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(ci, zA, wA);
+    __builtin_amdgcn_sched_barrier(0);
+    load_z(ci + 2, zA);
+    load_w(ci + 2, wA);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(ci + 1, zB, wB);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (Cin & 1) compute(Cin - 1, zA, wA);
+}
+
 }  // namespace
 
 extern "C" {
@@ -455,18 +600,27 @@ int nq_head_forward(const float* x, const float* wt, int ld, const float* bias, 
   const char* hv = getenv("NQ_HEAD_FWD");   // NQ_HEAD_FWD=1: the LDS-staged kernel (A/B runs; read per call)
   const bool v1 = hv && hv[0] == '1';
   if (k == 3 && Cout == 3 && (W & 3) == 0 && (ld & 3) == 0 && (int64_t)B * Cin * H * W * 4 < 0xFFFFFF00ll && !v1) {
-    constexpr int R = 5, D = 4;
+    // R output rows per wave; NQ_HEAD_RD=r picks another compiled value (timing runs)
+    int R = 4;
+    if (const char* rd = getenv("NQ_HEAD_RD")) R = atoi(rd);
     HeadFwd2Args a;
     a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.ld = ld;
     a.strips = (W + 255) / 256; a.rblocks = (H + R - 1) / R;
     a.x_bytes = (unsigned)((int64_t)B * Cin * H * W * 4);
     const int waves = B * a.strips * a.rblocks;
     dim3 g2((unsigned)((waves + 3) / 4)), blk2(256);
-    const size_t lds = (size_t)Cin * 9 * 16;
-    if (lds > 64 * 1024) return NQ_ERR_UNSUPPORTED;
-    if (epi == NQ_EPI_TANH) hipLaunchKernelGGL((head_fwd2_kernel<R, D, 3, true>), g2, blk2, lds, st, x, wt, bias, y, a);
-    else hipLaunchKernelGGL((head_fwd2_kernel<R, D, 3, false>), g2, blk2, lds, st, x, wt, bias, y, a);
-    return nq_launch_status();
+    const size_t lds = 0;
+    const bool th = epi == NQ_EPI_TANH;
+#define NQ_HF2(R_)                                                                                              \
+  if (R == R_) {                                                                                                \
+    if (th) hipLaunchKernelGGL((head_fwd2_kernel<R_, 3, true>), g2, blk2, lds, st, x, wt, bias, y, a);          \
+    else hipLaunchKernelGGL((head_fwd2_kernel<R_, 3, false>), g2, blk2, lds, st, x, wt, bias, y, a);            \
+    return nq_launch_status();                                                                                  \
+  }
+    NQ_HF2(4)
+    NQ_HF2(5)
+#undef NQ_HF2
+    return NQ_ERR_UNSUPPORTED;
   }
   const int tiles_x = (W + 63) / 64, tiles = tiles_x * ((H + 15) / 16);
   dim3 g((unsigned)(tiles * B)), blk(256);
@@ -481,6 +635,27 @@ int nq_head_forward(const float* x, const float* wt, int ld, const float* bias, 
 // dy (B,Cout,H,W) -> out = d/dx (B,Cin,H,W) [* gelu'(zprev)] stored PixelUnshuffle(r)-ed
 int nq_head_dgrad(const float* dy, const float* wt, int ld, const float* zprev, float* out, int B, int Cin, int H, int W,
                   int Cout, int k, int r, hipStream_t st) {
+  // the shipped head (3x3, 3 image channels, GELU + PixelShuffle(2) below it): the streaming kernel; 32-bit buffer offsets
+  const char* hv = getenv("NQ_HEAD_DGRAD");   // NQ_HEAD_DGRAD=1: the LDS-staged kernel (A/B runs; read per call)
+  if (k == 3 && Cout == 3 && r == 2 && zprev && (W % 4 == 0) && (H % 2 == 0) && (int64_t)B * Cin * H * W * 4 < 0xFFFFFF00ll &&
+      !(hv && hv[0] == '1')) {
+    int R = 4;
+    if (const char* rd = getenv("NQ_HEAD_DG_R")) R = atoi(rd);
+    HeadDg2Args a;
+    a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.ld = ld;
+    a.strips = (W + 255) / 256; a.rblocks = (H + R - 1) / R;
+    a.dy_bytes = (unsigned)((int64_t)B * Cout * H * W * 4);
+    a.z_bytes = (unsigned)((int64_t)B * Cin * H * W * 4);
+    const int waves = B * a.strips * a.rblocks;
+    dim3 g2((unsigned)((waves + 3) / 4)), blk2(256);
+    const size_t lds = (size_t)Cin * 28 * 4;
+    if (lds <= 64 * 1024) {
+      if (R == 2) hipLaunchKernelGGL((head_dgrad2_kernel<2, 3>), g2, blk2, lds, st, dy, wt, zprev, out, a);
+      else if (R == 4) hipLaunchKernelGGL((head_dgrad2_kernel<4, 3>), g2, blk2, lds, st, dy, wt, zprev, out, a);
+      else return NQ_ERR_UNSUPPORTED;
+      return nq_launch_status();
+    }
+  }
   // r == 2 fast path: 8 pixels per thread (tile 32 x 64) when W % 8 == 0 and k <= 3, else 4 (tile 16 x 64)
   const bool r2 = (r == 2) && (W % 4 == 0) && (H % 2 == 0);
   const bool px8 = r2 && (W % 8 == 0) && k <= 3;

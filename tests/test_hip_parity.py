@@ -977,6 +977,30 @@ def test_head_forward_streaming_kernel(ops, shape, epi_tanh, monkeypatch):
     assert torch.equal(y_new, ops.conv_forward_raw(x, wt, dims, b, 3, 3, epi, 1)[0])   # deterministic
 
 
+@pytest.mark.parametrize("shape", [(2, 37, 640, 1280), (1, 24, 320, 640), (3, 5, 18, 36), (1, 37, 6, 260), (2, 9, 64, 1028)])
+def test_head_data_gradient_streaming_kernel(ops, shape, monkeypatch):
+    """head_dgrad2 (round 3: register-streaming; the 3-channel dY neighbourhood of a 256-column x 4-row block in registers,
+    gelu' one channel ahead, 8-byte un-shuffled stores) against float64 and against the LDS-staged kernel it replaces
+    (NQ_HEAD_DGRAD=1).  Bound: 2e-6 of the output scale."""
+    B, cin, H, W = shape
+    g = torch.Generator().manual_seed(6)
+    w = (torch.randn(3, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(DEV)
+    dy = torch.randn(B, 3, H, W, generator=g).to(DEV)
+    z = torch.randn(B, cin, H, W, generator=g).to(DEV)
+    _, _, wb, dims_b = ops.weight_layouts(w, True)
+    f = lambda: ops.conv_forward_raw(dy, wb, dims_b, None, cin, 3, ops.EPI_DGRAD_GELU, 2, zprev=z)[0]
+    monkeypatch.setenv("NQ_HEAD_DGRAD", "1")
+    y_old = f()
+    monkeypatch.setenv("NQ_HEAD_DGRAD", "0")
+    y_new = f()
+    ref = F.pixel_unshuffle(F.conv_transpose2d(dy.double().cpu(), w.double().cpu(), padding=1) * z.double().cpu(), 2)
+    scale = float(ref.abs().max())
+    assert y_new.shape == ref.shape
+    assert float((y_new.cpu().double() - ref).abs().max()) <= 2e-6 * scale
+    assert float((y_new - y_old).abs().max()) <= 2e-6 * scale
+    assert torch.equal(y_new, f())
+
+
 def test_two_interleaved_decoders_keep_their_own_state(ops, golden):
     """The in-process hand-offs live on the decoder's own autograd node (round 3): the fused loss tail's
     head gradient / bias gradient (img.grad_fn.nq_head), the data-parallel arena hook captured at forward time

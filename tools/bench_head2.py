@@ -26,5 +26,10 @@ ref = torch.tanh(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), 
 print("old vs f64", (y_old - ref).abs().max().item(), "new vs f64", (y_new - ref).abs().max().item(), "old vs new", (y_old - y_new).abs().max().item())
 for rnd in range(3):
     os.environ["NQ_HEAD_FWD"] = "1"; a = t(f)
-    os.environ["NQ_HEAD_FWD"] = "0"; c = t(f)
-    print(f"round {rnd}: LDS-staged {a:.1f} us | streaming {c:.1f} us  ({262.1e6 / c / 1e6:.2f} TB/s algorithmic)")
+    os.environ["NQ_HEAD_FWD"] = "0"
+    row = []
+    for rd in (sys.argv[1:] or ["5,8"]):
+        os.environ["NQ_HEAD_RD"] = rd
+        c = t(f)
+        row.append(f"{rd}: {c:.1f} us ({262.1e6 / c / 1e6:.2f} TB/s)")
+    print(f"round {rnd}: LDS-staged {a:.1f} us | streaming " + " | ".join(row))
