@@ -112,6 +112,25 @@ typedef struct nq_adam_seg {
   float* v;
   int64_t n;
 } nq_adam_seg;
+/* d(alpha) (+ regulariser gradient where reg_weight != 0) and torch.optim.Adam's update of alpha in ONE pass over the
+ * rounding variables (calib_model.py:170-226: loss.backward(); optimizer.step()): per element the arithmetic of
+ * nq_adaround_backward_multi followed by nq_adam_step_multi, d(alpha) is never stored; alpha, m, v are updated in place and
+ * bit-identical to the two launches.  dyn != NULL: {reg_b, regulariser gate, lr/(1-beta1^t), sqrt(1-beta2^t)} are read from
+ * that device array (nq_step_prologue) instead of the host arguments. */
+typedef struct nq_ada_adam_seg {
+  const float* x;
+  const float* gy;
+  float* alpha;
+  const float* delta;
+  const float* zp;
+  float* m;
+  float* v;
+  int64_t rows, row_len;
+  int per_row, n_levels;
+  float reg_weight;
+} nq_ada_adam_seg;
+int nq_adaround_adam_multi(const nq_ada_adam_seg* segs, int nseg, float reg_b, float step_size, float beta1, float beta2, float eps,
+                           float bc2_sqrt, const float* dyn, nq_stream_t stream);
 int nq_adaround_forward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream);
 int nq_adaround_backward_multi(const nq_ada_seg* segs, int nseg, float reg_b, nq_stream_t stream);
 int nq_adam_step_multi(const nq_adam_seg* segs, int nseg, float step_size, float beta1, float beta2, float eps,
@@ -125,6 +144,10 @@ int nq_adam_step_multi(const nq_adam_seg* segs, int nseg, float step_size, float
  * host arguments -- same values, same arithmetic, so a replayed iteration is bit-identical to an eagerly launched one. */
 int nq_step_prologue(const int64_t* order, const float* scal, int* step, int64_t* cur_idx, float* cur_scal, int B, int nscal,
                      nq_stream_t stream);
+/* The same, plus the batch's rows of a table gathered in the same launch: out[t] = table[cur_idx[t]] (row_len floats each),
+ * i.e. the decoder inputs cali_data[idx] (calib_model.py:150, :201) without a separate index_select launch. */
+int nq_step_prologue_gather(const int64_t* order, const float* scal, int* step, int64_t* cur_idx, float* cur_scal, int B, int nscal,
+                            const float* table, int64_t table_rows, int64_t row_len, float* out, nq_stream_t stream);
 int nq_adaround_backward_multi_dyn(const nq_ada_seg* segs, int nseg, const float* dyn, nq_stream_t stream);
 int nq_adam_step_multi_dyn(const nq_adam_seg* segs, int nseg, const float* dyn, float beta1, float beta2, float eps,
                            nq_stream_t stream);
@@ -240,6 +263,29 @@ int nq_conv_wgrad3_swapped(const float* x, const float* dy, float* dw, float* ws
 int64_t nq_conv_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
 int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                   int k, int x_gelu, nq_stream_t stream);
+
+/* Deferred slab reduction (round 3).  The weight-gradient kernels above split K over workgroups into slabs and finish with a
+ * fixed-order reduction launch each (five ~10 us launches per HNeRV-3M iteration).  The *_slabs variants run ONLY the
+ * split kernel and describe the pending reduction in *seg (slab / dw / db pointers stay owned by the caller until it ran);
+ * nq_wgrad_reduce_multi performs up to 16 pending reductions per launch, each with the same summation order as the
+ * single-tensor entry point -- results are bit-identical to nq_conv_wgrad3 / nq_conv_wgrad3_swapped / nq_conv_wgrad.
+ * seg->nsplit == 0 on return: the kernel wrote dw / db itself (tiny 1x1 problems), nothing is pending. */
+typedef struct nq_wgr_seg {
+  const float* slab;     /* [nsplit][co_pad][n_pad] */
+  const float* slab_db;  /* [nsplit][co_pad] or NULL */
+  float* dw;
+  float* db;             /* or NULL */
+  int Cout, N, co_pad, n_pad, nsplit;
+  int swap_kk;           /* > 0: role-swapped problem, dw[ci][co][kk-1-tap] = R[co][ci][tap] (nq_conv_wgrad3_swapped) */
+  int sg;                /* split groups per output (1, 4 or 16): fixes the summation order */
+} nq_wgr_seg;
+int nq_conv_wgrad3_slabs(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+                         int k, nq_wgr_seg* seg, nq_stream_t stream);
+int nq_conv_wgrad3_swapped_slabs(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int H, int W, int Cout,
+                                 int k, nq_wgr_seg* seg, nq_stream_t stream);
+int nq_conv_wgrad_slabs(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+                        int k, int x_gelu, nq_wgr_seg* seg, nq_stream_t stream);
+int nq_wgrad_reduce_multi(const nq_wgr_seg* segs, int nseg, nq_stream_t stream);
 
 /* Backward of PixelShuffle(r)+GELU: dconv (B,C*r*r,H,W) = unshuffle(da * z), da and z (B,C,H*r,W*r), z = the saved
  * derivative output of a NQ_EPI_PS_GELU forward. */

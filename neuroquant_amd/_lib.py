@@ -41,6 +41,19 @@ class FwhtSeg(Structure):
                 ("n_out", c_int)]
 
 
+class AdaAdamSeg(Structure):
+    """nq_ada_adam_seg (include/nq_hip.h)."""
+    _fields_ = [("x", c_void_p), ("gy", c_void_p), ("alpha", c_void_p), ("delta", c_void_p), ("zp", c_void_p), ("m", c_void_p),
+                ("v", c_void_p), ("rows", c_int64), ("row_len", c_int64), ("per_row", c_int), ("n_levels", c_int),
+                ("reg_weight", c_float)]
+
+
+class WgrSeg(Structure):
+    """nq_wgr_seg (include/nq_hip.h): one pending slab reduction."""
+    _fields_ = [("slab", c_void_p), ("slab_db", c_void_p), ("dw", c_void_p), ("db", c_void_p), ("Cout", c_int), ("N", c_int),
+                ("co_pad", c_int), ("n_pad", c_int), ("nsplit", c_int), ("swap_kk", c_int), ("sg", c_int)]
+
+
 class AdamSeg(Structure):
     """nq_adam_seg (include/nq_hip.h)."""
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64)]
@@ -72,10 +85,12 @@ def _load():
     sig("nq_adaround_init", I, P, P, P, P, P, P, L, L, I, P)
     sig("nq_adaround_forward", I, P, P, P, P, P, P, L, L, I, I, I, P)
     sig("nq_adaround_backward", I, P, P, P, P, P, P, L, L, I, I, F, F, P)
+    sig("nq_adaround_adam_multi", I, POINTER(AdaAdamSeg), I, F, F, F, F, F, F, P, P)
     sig("nq_adaround_forward_multi", I, POINTER(AdaSeg), I, P)
     sig("nq_adaround_backward_multi", I, POINTER(AdaSeg), I, F, P)
     sig("nq_adam_step_multi", I, POINTER(AdamSeg), I, F, F, F, F, F, P)
     sig("nq_step_prologue", I, P, P, P, P, P, I, I, P)
+    sig("nq_step_prologue_gather", I, P, P, P, P, P, I, I, P, L, L, P, P)
     sig("nq_adaround_backward_multi_dyn", I, POINTER(AdaSeg), I, P, P)
     sig("nq_adam_step_multi_dyn", I, POINTER(AdamSeg), I, P, F, F, F, P)
     sig("nq_reduce_ws_floats", L, L)
@@ -100,6 +115,10 @@ def _load():
     sig("nq_conv_wgrad3_plan", I, I, I, I, I, I, I, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int))
     sig("nq_conv_wgrad3", I, P, P, P, P, P, I, I, I, I, I, I, P)
     sig("nq_conv_wgrad3_swapped", I, P, P, P, P, I, I, I, I, I, I, P)
+    sig("nq_conv_wgrad3_slabs", I, P, P, P, P, P, I, I, I, I, I, I, POINTER(WgrSeg), P)
+    sig("nq_conv_wgrad3_swapped_slabs", I, P, P, P, P, I, I, I, I, I, I, POINTER(WgrSeg), P)
+    sig("nq_conv_wgrad_slabs", I, P, P, P, P, P, I, I, I, I, I, I, I, POINTER(WgrSeg), P)
+    sig("nq_wgrad_reduce_multi", I, POINTER(WgrSeg), I, P)
     sig("nq_conv_wgrad_ws_floats", L, I, I, I, I, I, I)
     sig("nq_conv_wgrad", I, P, P, P, P, P, I, I, I, I, I, I, I, P)
     sig("nq_ps_gelu_backward", I, P, P, P, I, I, I, I, I, P)
@@ -115,9 +134,10 @@ def _load():
 EXPORTS = (
     "nq_abi_version", "nq_error_string", "nq_scale_init_max", "nq_uaq_forward", "nq_uaq_backward",
     "nq_adaround_init", "nq_adaround_forward", "nq_adaround_backward", "nq_reduce_ws_floats", "nq_round_loss", "nq_round_loss_backward",
-    "nq_adam_step", "nq_adaround_forward_multi", "nq_adaround_backward_multi", "nq_adam_step_multi", "nq_step_prologue", "nq_adaround_backward_multi_dyn", "nq_adam_step_multi_dyn", "nq_fwht", "nq_fwht_multi", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
+    "nq_adam_step", "nq_adaround_adam_multi", "nq_adaround_forward_multi", "nq_adaround_backward_multi", "nq_adam_step_multi", "nq_step_prologue", "nq_step_prologue_gather", "nq_adaround_backward_multi_dyn", "nq_adam_step_multi_dyn", "nq_fwht", "nq_fwht_multi", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
     "nq_conv3_supported", "nq_conv3_weight_bytes", "nq_weight_layout3", "nq_weight_layout3_multi", "nq_weight_layouts_multi", "nq_conv_forward3_ws_floats", "nq_conv_forward3",
     "nq_conv_wgrad3_supported", "nq_conv_wgrad3_ws_floats", "nq_conv_wgrad3_plan", "nq_conv_wgrad3", "nq_conv_wgrad3_swapped",
+    "nq_conv_wgrad3_slabs", "nq_conv_wgrad3_swapped_slabs", "nq_conv_wgrad_slabs", "nq_wgrad_reduce_multi",
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",
     "nq_channel_sum", "nq_l2_loss_tanh_head", "nq_frame_sse", "nq_gather_frames_u8",
 )

@@ -100,6 +100,10 @@ inline WgradPlan plan_wgrad(int B, int Cin, int H, int W, int Cout, int k) {
   // one full wave of workgroups: 256 CUs x 2 resident workgroups (the kernels sit at 170-230 VGPRs), no ragged tail
   int ns = 512 / tiles;
   if (ns > nseg) ns = nseg;
+  // every split writes a whole co_pad x n_pad slab: with only a few segments per split the slab traffic IS the kernel
+  // (HNeRV-3M dec2, 77 -> 1024 at 10x20: 20 segments, 16 splits x 3.1 MB written and read back for 1.25 segments of
+  // work each) -> at least 4 segments per split
+  if (ns > nseg / 4) ns = nseg / 4;
   if (ns > 256) ns = 256;
   if (ns < 1) ns = 1;
   p.nsplit = ns;
@@ -301,10 +305,25 @@ int64_t nq_conv_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
   return (int64_t)p.nsplit * p.co_pad * ((int64_t)p.n_pad + 1);
 }
 
+static int conv_wgrad_impl(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W,
+                           int Cout, int k, int x_gelu, nq_wgr_seg* seg, nq_stream_t stream);
+
 int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                   int k, int x_gelu, nq_stream_t stream) {
+  return conv_wgrad_impl(x, dy, dw, db, ws, B, Cin, H, W, Cout, k, x_gelu, nullptr, stream);
+}
+
+int nq_conv_wgrad_slabs(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+                        int k, int x_gelu, nq_wgr_seg* seg, nq_stream_t stream) {
+  if (!seg) return NQ_ERR_INVALID;
+  return conv_wgrad_impl(x, dy, dw, db, ws, B, Cin, H, W, Cout, k, x_gelu, seg, stream);
+}
+
+static int conv_wgrad_impl(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W,
+                           int Cout, int k, int x_gelu, nq_wgr_seg* seg, nq_stream_t stream) {
   if (!x || !dy || !dw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
   if (!ks_ok(k)) return NQ_ERR_UNSUPPORTED;
+  if (seg) *seg = nq_wgr_seg{nullptr, nullptr, dw, db, Cout, Cin * k * k, 0, 0, 0, 0, 1};
   if (!x_gelu && nq_tiny_pw_supported(B, Cin, H, W, Cout, k))
     return nq_tiny_pw_wgrad(x, dy, dw, db, B, Cin, H, W, Cout, nq_s(stream));
   WgradPlan p = plan_wgrad(B, Cin, H, W, Cout, k);
@@ -319,6 +338,10 @@ int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* 
   }
   if (rc != NQ_OK) return rc;
   const int N = Cin * k * k;
+  if (seg) {   // deferred: the sequential fixed-order sum over the splits (sg = 1) runs in nq_wgrad_reduce_multi
+    *seg = nq_wgr_seg{slab, db ? slab_db : nullptr, dw, db, Cout, N, p.co_pad, p.n_pad, p.nsplit, 0, 1};
+    return NQ_OK;
+  }
   int64_t total = (int64_t)Cout * N + Cout;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, slab, slab_db, dw, db, Cout,
                      N, p.co_pad, p.n_pad, p.nsplit);

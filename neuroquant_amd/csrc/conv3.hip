@@ -48,64 +48,87 @@ inline int64_t total_steps3(int Cin, int k) {
   return tail8_of(Cin) ? (int64_t)(nchunk - 1) * nst_of(k) + nst8_of(k) : (int64_t)nchunk * nst_of(k);
 }
 
-// One thread per 16-byte fragment slot (c, s, tile, kq, co): 8 consecutive channels of one tap, split into bf16 hi/lo.
+// Operand of the bf16x3 kernels: 16-byte fragment slots [global k-step][plane hi/lo][co tile][kq][MT] of 8 bf16 k-values.
 // transposed = 0: logical conv == the stored conv, src(co, ch, tap) = w[co][ch][tap]
 // transposed = 1: data gradient, logical (Cin=Cout_w -> Cout=Cin_w): src(co, ch, tap) = w[ch][co][KK-1-tap]
 struct WL3 {
   const float* w;
   uint4* out;
   int Cin, Cout, KK, NST, NST8, nchunk, tail8, co_tiles, MT, transposed;
+  int co16;        // 16-channel groups of output channels: ceil(co_tiles*MT / 16)
   int64_t slots;
 };
-__device__ __forceinline__ void wl3_slot(const WL3& p, int64_t i) {
-  const int MT = p.MT, co_tiles = p.co_tiles, NST = p.NST, Cin = p.Cin, Cout = p.Cout, KK = p.KK;
-  const float* __restrict__ w = p.w;
-  const int co_l = (int)(i % MT);
-  const int kq = (int)((i / MT) % 4);
-  const int tile = (int)((i / (4 * MT)) % co_tiles);
-  // global k-step gs -> (chunk c, step s): full chunks have NST steps, a tail8 chunk (always the last) NST8
-  const int64_t gs = i / ((int64_t)4 * MT * co_tiles);
-  const int nfull = p.nchunk - p.tail8;
-  int c, s;
-  if (gs < (int64_t)nfull * NST) {
-    c = (int)(gs / NST);
-    s = (int)(gs - (int64_t)c * NST);
+// k-value e (0..7) of lane group kq at k-step s of a chunk -> (channel within the chunk, tap); tap >= KK: zero weight.
+//   full chunk : 2 octets x 2 taps per step   ch = (kq&1)*8 + e, tap = 2s + (kq>>1)
+//   tail8 chunk: 1 octet x 4 taps per step    ch = e,            tap = 4s + kq          (Conv3Args::tail8)
+__device__ __forceinline__ void wl3_elem(bool t8, int s, int kq, int e, int& ch, int& tap) {
+  if (t8) {
+    ch = e;
+    tap = 4 * s + kq;
   } else {
-    c = nfull;
-    s = (int)(gs - (int64_t)nfull * NST);
+    ch = (kq & 1) * 8 + e;
+    tap = 2 * s + (kq >> 1);
   }
+}
+
+// One workgroup per (16-channel chunk c of the logical input channels, group of 16 logical output channels): the 16 x 16 x KK
+// weights it needs are 16 CONTIGUOUS runs of 16*KK floats in the stored tensor (rows = co for the forward operand, = ch
+// for the transposed one), loaded coalesced into LDS; the fragment slots are then assembled from LDS and stored 16 bytes
+// per thread, 256 contiguous bytes per 16 lanes.  (Round 2's kernel gathered the 8 values of a slot straight from global
+// memory at a stride of KK or Cout*KK floats: 22.6 us for the layers of HNeRV-3M, most of it uncoalesced reads.)
+constexpr int WL3_KKMAX = 25;
+__device__ __forceinline__ void wl3_tile(const WL3& p, int c, int g16, float* __restrict__ T /* [16][16*KK (+1)] */) {
+  const int KK = p.KK, RS = 16 * KK + 1;   // row stride: odd -> the 16 rows of a column land in different banks
+  const int tid = threadIdx.x;
+  const int nfull = p.nchunk - p.tail8;
   const bool t8 = p.tail8 && c == nfull;
-  const int co = tile * MT + co_l;
-  const int tap = t8 ? 4 * s + kq : 2 * s + (kq >> 1);
-  const int ch0 = t8 ? c * CC : c * CC + (kq & 1) * 8;
-  unsigned hi[4], lo[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float v[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int ch = ch0 + 2 * j + t;
-      float x = 0.f;
-      if (tap < KK && ch < Cin && co < Cout)
-        x = p.transposed ? w[((int64_t)ch * Cout + co) * KK + (KK - 1 - tap)] : w[((int64_t)co * Cin + ch) * KK + tap];
-      v[t] = x;
-    }
-    __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1];
-    __bf16 l0 = (__bf16)(v[0] - (float)h0), l1 = (__bf16)(v[1] - (float)h1);
-    hi[j] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
-    lo[j] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+  const int nst = t8 ? p.NST8 : p.NST;
+  const int64_t gs0 = t8 ? (int64_t)nfull * p.NST : (int64_t)c * p.NST;
+  // rows a = 0..15, columns (b, tap): forward a = co (g16*16 + a), b = ch (c*16 + b); transposed a = ch, b = co
+  const int Ra = p.transposed ? p.Cin : p.Cout;            // valid extent of the row index (stored tensor's dim 0)
+  const int Cb = p.transposed ? p.Cout : p.Cin;            // stored tensor's dim 1
+  const int a0 = p.transposed ? c * 16 : g16 * 16, b0 = p.transposed ? g16 * 16 : c * 16;
+  for (int e = tid; e < 16 * 16 * KK; e += 256) {
+    const int a = e / (16 * KK), rem = e - a * (16 * KK);
+    const int bb = rem / KK;
+    float v = 0.f;
+    if (a0 + a < Ra && b0 + bb < Cb) v = p.w[((int64_t)(a0 + a) * Cb + b0) * KK + rem];
+    T[a * RS + rem] = v;
   }
-  // [c][s][plane][tile][kq][MT]
-  const int64_t step = gs;
-  const int64_t plane_stride = (int64_t)co_tiles * 4 * MT;
-  const int64_t base = step * 2 * plane_stride + (int64_t)tile * 4 * MT + kq * MT + co_l;
-  p.out[base] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-  p.out[base + plane_stride] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  __syncthreads();
+  const int MT = p.MT;
+  const int64_t plane_stride = (int64_t)p.co_tiles * 4 * MT;
+  for (int sl = tid; sl < nst * 4 * 16; sl += 256) {
+    const int col = sl & 15, kq = (sl >> 4) & 3, st = sl >> 6;
+    const int co = g16 * 16 + col;
+    if (co >= p.co_tiles * MT) continue;
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float v[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        int ch, tap;
+        wl3_elem(t8, st, kq, 2 * j + t, ch, tap);
+        float x = 0.f;
+        if (tap < KK) x = p.transposed ? T[ch * RS + col * KK + (KK - 1 - tap)] : T[col * RS + ch * KK + tap];
+        v[t] = x;
+      }
+      __bf16 h0 = (__bf16)v[0], h1 = (__bf16)v[1];
+      __bf16 l0 = (__bf16)(v[0] - (float)h0), l1 = (__bf16)(v[1] - (float)h1);
+      hi[j] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+      lo[j] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+    }
+    const int tile = co / MT, co_l = co - tile * MT;
+    const int64_t base = (gs0 + st) * 2 * plane_stride + (int64_t)tile * 4 * MT + kq * MT + co_l;
+    p.out[base] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    p.out[base + plane_stride] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+  }
 }
 
 __global__ __launch_bounds__(256) void weight_layout3_kernel(WL3 p) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < p.slots) wl3_slot(p, i);
+  __shared__ float T[16 * (16 * WL3_KKMAX + 1)];
+  wl3_tile(p, (int)blockIdx.x / p.co16, (int)blockIdx.x % p.co16, T);
 }
 
 // all layers' operands (forward and data-gradient) in ONE launch: the table travels as a kernel argument
@@ -116,10 +139,11 @@ struct WL3Multi {
   int nseg;
 };
 __global__ __launch_bounds__(256) void weight_layout3_multi_kernel(WL3Multi t) {
+  __shared__ float T[16 * (16 * WL3_KKMAX + 1)];
   int k = 0;
   while (k + 1 < t.nseg && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
-  const int64_t i = (int64_t)(blockIdx.x - t.blk0[k]) * 256 + threadIdx.x;
-  if (i < t.s[k].slots) wl3_slot(t.s[k], i);
+  const int blk = (int)blockIdx.x - t.blk0[k];
+  wl3_tile(t.s[k], blk / t.s[k].co16, blk % t.s[k].co16, T);
 }
 
 // split-K of the forward / data-gradient kernel over 16-channel chunks when the pixel x channel grid alone cannot fill
@@ -262,6 +286,56 @@ __global__ __launch_bounds__(256) void wgrad3_reduce_kernel(const float* __restr
   }
 }
 
+// Several pending reductions in ONE launch (nq_wgrad_reduce_multi): per segment the arithmetic of wgrad3_reduce_kernel<sg>
+// (sg = 4 / 16) or of the sequential fp32 reduction (sg = 1), so results are bit-identical to the single-tensor launches.
+constexpr int WGR_MAXSEG = 16;
+struct WGRMulti {
+  nq_wgr_seg s[WGR_MAXSEG];
+  int blk0[WGR_MAXSEG + 1];
+  int nseg;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WGRMulti t) {
+  __shared__ float part[256];
+  int k = 0;
+  while (k + 1 < t.nseg && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
+  const nq_wgr_seg& q = t.s[k];
+  const int SG = q.sg, OG = 256 / SG;
+  const int o = threadIdx.x % OG, g = threadIdx.x / OG;
+  const int N = q.N, Cout = q.Cout, nsplit = q.nsplit;
+  const int64_t i = (int64_t)((int)blockIdx.x - t.blk0[k]) * OG + o;
+  const int64_t total = (int64_t)Cout * N;
+  float s = 0.f;
+  if (i < total) {
+    const int co = (int)(i / N), n = (int)(i - (int64_t)co * N);
+    const float* p = q.slab + (int64_t)co * q.n_pad + n;
+    const int64_t stride = (int64_t)q.co_pad * q.n_pad;
+#pragma unroll 4
+    for (int j = g; j < nsplit; j += SG) s += p[j * stride];
+  } else if (q.db && i < total + Cout) {
+    const int co = (int)(i - total);
+#pragma unroll 4
+    for (int j = g; j < nsplit; j += SG) s += q.slab_db[(int64_t)j * q.co_pad + co];
+  }
+  if (SG > 1) {   // block-uniform
+    part[g * OG + o] = s;
+    __syncthreads();
+    if (g != 0) return;
+    s = part[o];
+    for (int j = 1; j < SG; ++j) s += part[j * OG + o];
+  }
+  if (i < total) {
+    if (q.swap_kk > 0) {
+      const int co = (int)(i / N), n = (int)(i - (int64_t)co * N);
+      const int ci = n / q.swap_kk, tap = n - ci * q.swap_kk;
+      q.dw[((int64_t)ci * Cout + co) * q.swap_kk + (q.swap_kk - 1 - tap)] = s;
+    } else {
+      q.dw[i] = s;
+    }
+  } else if (q.db && i < total + Cout) {
+    q.db[(int)(i - total)] = s;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -301,13 +375,14 @@ static bool wl3_fill(WL3& p, const float* w, void* wt3, int Cin, int Cout, int k
   p.MT = 16 * mi; p.co_tiles = (Cout + p.MT - 1) / p.MT; p.nchunk = (Cin + CC - 1) / CC; p.transposed = transposed;
   p.tail8 = tail8_of(Cin) ? 1 : 0;
   p.slots = total_steps3(Cin, k) * p.co_tiles * 4 * p.MT;
+  p.co16 = (p.co_tiles * p.MT + 15) / 16;
   return true;
 }
 
 int nq_weight_layout3(const float* w, void* wt3, int Cin, int Cout, int k, int transposed, nq_stream_t stream) {
   WL3 p;
   if (!wl3_fill(p, w, wt3, Cin, Cout, k, transposed)) return NQ_ERR_INVALID;
-  hipLaunchKernelGGL(weight_layout3_kernel, dim3((unsigned)((p.slots + 255) / 256)), dim3(256), 0, nq_s(stream), p);
+  hipLaunchKernelGGL(weight_layout3_kernel, dim3((unsigned)(p.nchunk * p.co16)), dim3(256), 0, nq_s(stream), p);
   return nq_launch_status();
 }
 
@@ -321,7 +396,7 @@ int nq_weight_layout3_multi(const nq_wl3_seg* segs, int nseg, nq_stream_t stream
       const nq_wl3_seg& h = segs[base + i];
       if (!wl3_fill(t.s[i], h.w, h.wt3, h.Cin, h.Cout, h.k, h.transposed)) return NQ_ERR_INVALID;
       t.blk0[i] = blocks;
-      blocks += (int)((t.s[i].slots + 255) / 256);
+      blocks += t.s[i].nchunk * t.s[i].co16;
     }
     t.blk0[t.nseg] = blocks;
     hipLaunchKernelGGL(weight_layout3_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, nq_s(stream), t);
@@ -365,21 +440,62 @@ int64_t nq_conv_wgrad3_ws_floats(int B, int Cin, int H, int W, int Cout, int k) 
 }
 
 static int conv_wgrad3_impl(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W,
-                            int Cout, int k, int swap_kk, nq_stream_t stream);
+                            int Cout, int k, int swap_kk, nq_wgr_seg* seg, nq_stream_t stream);
 
 int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                    int k, nq_stream_t stream) {
-  return conv_wgrad3_impl(x, dy, dw, db, ws, B, Cin, H, W, Cout, k, 0, stream);
+  return conv_wgrad3_impl(x, dy, dw, db, ws, B, Cin, H, W, Cout, k, 0, nullptr, stream);
 }
 
 int nq_conv_wgrad3_swapped(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int H, int W, int Cout, int k,
                            nq_stream_t stream) {
   // the kernel sees the exchanged problem: "x" = dy (Cout channels), "dy" = x (Cin channels)
-  return conv_wgrad3_impl(dy, x, dw, nullptr, ws, B, Cout, H, W, Cin, k, k * k, stream);
+  return conv_wgrad3_impl(dy, x, dw, nullptr, ws, B, Cout, H, W, Cin, k, k * k, nullptr, stream);
+}
+
+int nq_conv_wgrad3_slabs(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+                         int k, nq_wgr_seg* seg, nq_stream_t stream) {
+  if (!seg) return NQ_ERR_INVALID;
+  return conv_wgrad3_impl(x, dy, dw, db, ws, B, Cin, H, W, Cout, k, 0, seg, stream);
+}
+
+int nq_conv_wgrad3_swapped_slabs(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int H, int W, int Cout,
+                                 int k, nq_wgr_seg* seg, nq_stream_t stream) {
+  if (!seg) return NQ_ERR_INVALID;
+  return conv_wgrad3_impl(dy, x, dw, nullptr, ws, B, Cout, H, W, Cin, k, k * k, seg, stream);
+}
+
+int nq_wgrad_reduce_multi(const nq_wgr_seg* segs, int nseg, nq_stream_t stream) {
+  if (!segs || nseg < 0) return NQ_ERR_INVALID;
+  WGRMulti t;
+  t.nseg = 0;
+  int blocks = 0;
+  auto flush = [&]() {
+    if (t.nseg == 0) return;
+    t.blk0[t.nseg] = blocks;
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, nq_s(stream), t);
+    t.nseg = 0;
+    blocks = 0;
+  };
+  for (int i = 0; i < nseg; ++i) {
+    const nq_wgr_seg& h = segs[i];
+    if (h.nsplit == 0) continue;   // nothing pending (the kernel wrote dw itself)
+    if (!h.slab || !h.dw || h.Cout <= 0 || h.N <= 0 || h.nsplit < 0 || !(h.sg == 1 || h.sg == 4 || h.sg == 16) ||
+        (h.db && !h.slab_db))
+      return NQ_ERR_INVALID;
+    if (t.nseg == WGR_MAXSEG) flush();
+    t.s[t.nseg] = h;
+    t.blk0[t.nseg] = blocks;
+    const int og = 256 / h.sg;
+    blocks += (int)(((int64_t)h.Cout * h.N + h.Cout + og - 1) / og);
+    ++t.nseg;
+  }
+  flush();
+  return nq_launch_status();
 }
 
 static int conv_wgrad3_impl(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W,
-                            int Cout, int k, int swap_kk, nq_stream_t stream) {
+                            int Cout, int k, int swap_kk, nq_wgr_seg* seg, nq_stream_t stream) {
   if (!x || !dy || !dw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
   if (!(k == 3 || k == 5)) return NQ_ERR_UNSUPPORTED;
   if ((int64_t)Cout * H * W >= (1ll << 31) || (int64_t)Cin * H * W >= (1ll << 31)) return NQ_ERR_UNSUPPORTED;
@@ -392,6 +508,11 @@ static int conv_wgrad3_impl(const float* x, const float* dy, float* dw, float* d
   if (rc != NQ_OK) return rc;
   const int N = Cin * k * k;
   int64_t total = (int64_t)Cout * N + Cout;
+  if (seg) {   // deferred: describe the reduction, nq_wgrad_reduce_multi runs it (same split groups as below)
+    *seg = nq_wgr_seg{slab, db ? slab_db : nullptr, dw, db, Cout, N, p.co_pad, p.n_pad, p.nsplit, swap_kk,
+                      (total < 65536 && p.nsplit >= 16) ? 16 : 4};
+    return NQ_OK;
+  }
   if (total < 65536 && p.nsplit >= 16) {
     hipLaunchKernelGGL(wgrad3_reduce_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, slab, slab_db, dw, db,
                        Cout, N, p.co_pad, p.n_pad, p.nsplit, swap_kk);

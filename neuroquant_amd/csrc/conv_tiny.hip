@@ -105,8 +105,18 @@ int nq_tiny_pw_supported(int B, int Cin, int H, int W, int Cout, int k) {
 int nq_tiny_pw_forward(const float* x, const float* wt, const float* bias, float* y, float* z, const float* zprev, int B,
                        int Cin, int H, int W, int Cout, int ld, int r, int epi, hipStream_t st) {
   const int64_t total = (int64_t)B * H * W * Cout;
-  if (Cin > 256)
+  // threads per output = slices of the channel sum: each thread walks Cin / KSL channels through a chain of dependent
+  // fused multiply-adds fed by two L2-latency loads, so the kernel's time is that chain's length (round 2: 16 slices for
+  // the 1925-channel data gradient of HNeRV's dec1 = 120 links, 17.8 us; 64 slices = 30 links; 4 slices for the 92- and
+  // 160-channel forwards)
+  if (Cin > 1024)
+    hipLaunchKernelGGL(tiny_pw_fwd_kernel<64>, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, st, x, wt, bias, y, z, zprev,
+                       B, Cin, H, W, Cout, ld, r, epi);
+  else if (Cin > 256)
     hipLaunchKernelGGL(tiny_pw_fwd_kernel<16>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, st, x, wt, bias, y, z, zprev,
+                       B, Cin, H, W, Cout, ld, r, epi);
+  else if (Cin > 48)
+    hipLaunchKernelGGL(tiny_pw_fwd_kernel<4>, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, x, wt, bias, y, z, zprev,
                        B, Cin, H, W, Cout, ld, r, epi);
   else
     hipLaunchKernelGGL(tiny_pw_fwd_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, wt, bias, y, z, zprev,

@@ -387,6 +387,93 @@ __global__ __launch_bounds__(TPB) void adam_multi_kernel(AdamMulti t, float step
   }
 }
 
+// d(alpha) (+ regulariser gradient) and the Adam update of alpha in ONE pass (round 3): alpha is both the input of the
+// fake-quant backward and Adam's parameter, so d(alpha) never goes to memory (x, gy, alpha, m, v: 85 MB per HNeRV-3M
+// iteration instead of 117 MB in two launches).  Per element exactly ada_bwd_elem followed by adam_elem's arithmetic:
+// alpha / m / v are bit-identical to nq_adaround_backward_multi + nq_adam_step_multi.
+struct AdaAdamSegD {
+  const float* x;
+  const float* gy;
+  float* alpha;
+  const float* delta;
+  const float* zp;
+  float* m;
+  float* v;
+  int64_t n;
+  int row_len, per_row;
+  float qmax, reg_weight;
+  int vec;
+};
+struct AdaAdamMulti {
+  AdaAdamSegD s[MAXSEG];
+  int blk0[MAXSEG + 1];
+  int nseg;
+};
+__global__ __launch_bounds__(TPB) void adaround_adam_multi_kernel(AdaAdamMulti t, float reg_b, float step_size, float beta1,
+                                                                  float beta2, float eps, float bc2_sqrt,
+                                                                  const float* __restrict__ dyn) {
+  float gate = 1.f;
+  if (dyn) {   // per-step scalars from device memory (graph replays): {reg_b, regulariser gate, lr/(1-beta1^t), sqrt(1-beta2^t)}
+    reg_b = dyn[0];
+    gate = dyn[1];
+    step_size = dyn[2];
+    bc2_sqrt = dyn[3];
+  }
+  const int k = find_seg(t, blockIdx.x);
+  const AdaAdamSegD& sg = t.s[k];
+  const int64_t i0 = (int64_t)(blockIdx.x - t.blk0[k]) * (TPB * EPT) + 4 * threadIdx.x;
+  if (i0 >= sg.n) return;
+  const bool vec = sg.vec && (i0 + 3 < sg.n);
+  float xv[4], av[4], gv[4], mv[4], vv[4];
+  if (vec) {
+    const float4 x4 = *reinterpret_cast<const float4*>(sg.x + i0), a4 = *reinterpret_cast<const float4*>(sg.alpha + i0);
+    const float4 g4 = *reinterpret_cast<const float4*>(sg.gy + i0);
+    const float4 m4 = *reinterpret_cast<const float4*>(sg.m + i0), v4 = *reinterpret_cast<const float4*>(sg.v + i0);
+    xv[0] = x4.x; xv[1] = x4.y; xv[2] = x4.z; xv[3] = x4.w;
+    av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
+    gv[0] = g4.x; gv[1] = g4.y; gv[2] = g4.z; gv[3] = g4.w;
+    mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+    vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool in = i0 + j < sg.n;
+      xv[j] = in ? sg.x[i0 + j] : 0.f;
+      av[j] = in ? sg.alpha[i0 + j] : 0.f;
+      gv[j] = in ? sg.gy[i0 + j] : 0.f;
+      mv[j] = in ? sg.m[i0 + j] : 0.f;
+      vv[j] = in ? sg.v[i0 + j] : 0.f;
+    }
+  }
+  const int64_t row0 = sg.per_row ? i0 / sg.row_len : 0;
+  const int rem0 = sg.per_row ? (int)(i0 - row0 * sg.row_len) : 0;
+  const float rw = dyn ? sg.reg_weight * gate : sg.reg_weight;   // gate is exactly 0 or 1
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int64_t row = 0;
+    if (sg.per_row) row = (sg.row_len >= 4) ? row0 + ((rem0 + j >= sg.row_len) ? 1 : 0) : (i0 + j) / sg.row_len;
+    if (i0 + j >= sg.n) row = 0;
+    const float g = ada_bwd_elem(xv[j], gv[j], av[j], sg.delta[row], sg.zp[row], sg.qmax, rw, reg_b);
+    mv[j] = mv[j] + (1.f - beta1) * (g - mv[j]);
+    vv[j] = vv[j] * beta2 + (1.f - beta2) * (g * g);
+    const float denom = sqrtf(vv[j]) / bc2_sqrt + eps;
+    av[j] = av[j] - step_size * (mv[j] / denom);
+  }
+  if (vec) {
+    *reinterpret_cast<float4*>(sg.m + i0) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    *reinterpret_cast<float4*>(sg.v + i0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    *reinterpret_cast<float4*>(sg.alpha + i0) = make_float4(av[0], av[1], av[2], av[3]);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (i0 + j < sg.n) {
+        sg.m[i0 + j] = mv[j];
+        sg.v[i0 + j] = vv[j];
+        sg.alpha[i0 + j] = av[j];
+      }
+  }
+}
+
 inline unsigned blocks_per_row(int64_t row_len) { return (unsigned)((row_len + TPB * EPT - 1) / (TPB * EPT)); }
 inline dim3 row_grid(int64_t rows, int64_t row_len) { return dim3((unsigned)(rows * blocks_per_row(row_len)), 1, 1); }
 // rows x blocks-per-row must fit grid.x (2^31 - 1); any channel count a decoder can have does
@@ -508,6 +595,40 @@ __global__ __launch_bounds__(256) void step_prologue_kernel(const int64_t* __res
   if (t == 0) *step = s + 1;
 }
 
+// The prologue plus the gather of the batch's decoder inputs: blocks 1.. copy out[t] = table[order[step*B + t]] (they read
+// the step counter BEFORE block 0 can have advanced it?  No ordering exists between blocks, so block 0 does NOT advance it
+// here: every block reads *step, and the counter is advanced by the LAST block to finish -- a ticket in step[1]).
+__global__ __launch_bounds__(256) void step_prologue_gather_kernel(const int64_t* __restrict__ order, const float* __restrict__ scal,
+                                                                   int* __restrict__ step, int64_t* __restrict__ cur_idx,
+                                                                   float* __restrict__ cur_scal, int B, int nscal,
+                                                                   const float* __restrict__ table, int64_t table_rows,
+                                                                   int64_t row_len, float* __restrict__ out) {
+  __shared__ int last;
+  const int s = __hip_atomic_load(step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int t = threadIdx.x;
+  if (blockIdx.x == 0) {
+    if (t < B) cur_idx[t] = order[(int64_t)s * B + t];
+    if (t < nscal) cur_scal[t] = scal[(int64_t)s * nscal + t];
+  } else {
+    const int64_t per = ((int64_t)B * row_len + (gridDim.x - 2)) / (gridDim.x - 1);   // elements per gather block
+    const int64_t lo = (int64_t)(blockIdx.x - 1) * per, hi = min(lo + per, (int64_t)B * row_len);
+    for (int64_t e = lo + t; e < hi; e += 256) {
+      const int64_t f = e / row_len, j = e - f * row_len;
+      int64_t idx = order[(int64_t)s * B + f];
+      idx = idx < 0 ? 0 : (idx >= table_rows ? table_rows - 1 : idx);
+      out[e] = table[idx * row_len + j];
+    }
+  }
+  // the last block to arrive advances the step counter and re-arms the ticket (nobody reads *step after its ticket)
+  __syncthreads();
+  if (t == 0) last = (atomicAdd(step + 1, 1) == (int)gridDim.x - 1);
+  __syncthreads();
+  if (last && t == 0) {
+    step[1] = 0;
+    __hip_atomic_store(step, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 static int ada_multi(const nq_ada_seg* segs, int nseg, float reg_b, const float* dyn, bool bwd, nq_stream_t stream) {
   if (!segs || nseg <= 0) return NQ_ERR_INVALID;
   for (int base = 0; base < nseg; base += MAXSEG) {
@@ -558,8 +679,50 @@ int nq_step_prologue(const int64_t* order, const float* scal, int* step, int64_t
   return nq_launch_status();
 }
 
+int nq_step_prologue_gather(const int64_t* order, const float* scal, int* step, int64_t* cur_idx, float* cur_scal, int B, int nscal,
+                            const float* table, int64_t table_rows, int64_t row_len, float* out, nq_stream_t stream) {
+  if (!order || !scal || !step || !cur_idx || !cur_scal || B <= 0 || B > 256 || nscal <= 0 || nscal > 256 || !table || !out ||
+      table_rows <= 0 || row_len <= 0)
+    return NQ_ERR_INVALID;
+  // step = {counter, ticket}: two ints (the caller zeroes both)
+  const int64_t total = (int64_t)B * row_len;
+  int gb = (int)((total + 4095) / 4096);
+  if (gb < 1) gb = 1;
+  if (gb > 64) gb = 64;
+  hipLaunchKernelGGL(step_prologue_gather_kernel, dim3(1 + gb), dim3(256), 0, nq_s(stream), order, scal, step, cur_idx, cur_scal, B,
+                     nscal, table, table_rows, row_len, out);
+  return nq_launch_status();
+}
+
 static int adam_multi(const nq_adam_seg* segs, int nseg, float step_size, float beta1, float beta2, float eps, float bc2_sqrt,
                       const float* dyn, nq_stream_t stream);
+
+int nq_adaround_adam_multi(const nq_ada_adam_seg* segs, int nseg, float reg_b, float step_size, float beta1, float beta2, float eps,
+                           float bc2_sqrt, const float* dyn, nq_stream_t stream) {
+  if (!segs || nseg <= 0) return NQ_ERR_INVALID;
+  for (int base = 0; base < nseg; base += MAXSEG) {
+    AdaAdamMulti t;
+    t.nseg = (nseg - base < MAXSEG) ? nseg - base : MAXSEG;
+    int blocks = 0;
+    for (int k = 0; k < t.nseg; ++k) {
+      const nq_ada_adam_seg& h = segs[base + k];
+      if (!h.x || !h.gy || !h.alpha || !h.delta || !h.zp || !h.m || !h.v || h.rows <= 0 || h.row_len <= 0 ||
+          h.row_len > 0x7fffffffLL)
+        return NQ_ERR_INVALID;
+      AdaAdamSegD& d = t.s[k];
+      d.x = h.x; d.gy = h.gy; d.alpha = h.alpha; d.delta = h.delta; d.zp = h.zp; d.m = h.m; d.v = h.v;
+      d.n = h.rows * h.row_len; d.row_len = (int)h.row_len; d.per_row = h.per_row;
+      d.qmax = (float)(h.n_levels - 1); d.reg_weight = h.reg_weight;
+      d.vec = (((uintptr_t)h.x | (uintptr_t)h.gy | (uintptr_t)h.alpha | (uintptr_t)h.m | (uintptr_t)h.v) & 15) == 0;
+      t.blk0[k] = blocks;
+      blocks += (int)((d.n + TPB * EPT - 1) / (TPB * EPT));
+    }
+    t.blk0[t.nseg] = blocks;
+    hipLaunchKernelGGL(adaround_adam_multi_kernel, dim3((unsigned)blocks), dim3(TPB), 0, nq_s(stream), t, reg_b, step_size,
+                       beta1, beta2, eps, bc2_sqrt, dyn);
+  }
+  return nq_launch_status();
+}
 
 int nq_adam_step_multi(const nq_adam_seg* segs, int nseg, float step_size, float beta1, float beta2, float eps,
                        float bc2_sqrt, nq_stream_t stream) {

@@ -208,6 +208,17 @@ def step_prologue(order_tab, scal_tab, step_ctr, cur_idx, cur_scal):
                                      cur_scal.numel(), _stream()), "step_prologue")
 
 
+def step_prologue_gather(order_tab, scal_tab, step_ctr, cur_idx, cur_scal, table, out):
+    """nq_step_prologue_gather: step_prologue + out <- table[order_tab[*step]] in ONE launch (step_ctr: two int32 {counter,
+    ticket}, both zero at the start of an epoch)."""
+    table = _dev(table)
+    if step_ctr.numel() < 2 or out.shape[0] != cur_idx.numel() or out[0].numel() != table[0].numel() or not out.is_contiguous():
+        raise RuntimeError("step_prologue_gather: step_ctr needs two ints, out must be (B,) + table.shape[1:], contiguous")
+    L.check(L.lib().nq_step_prologue_gather(_p(order_tab), _p(scal_tab), _p(step_ctr), _p(cur_idx), _p(cur_scal), cur_idx.numel(),
+                                            cur_scal.numel(), _p(table), table.shape[0], table[0].numel(), _p(out), _stream()),
+            "step_prologue_gather")
+
+
 def adaround_backward_multi(items, reg_b=0.0, dyn=None):
     """items: [(x, gy, alpha, delta, zp, n_levels, reg_weight)] -> [d(alpha)] (+ regulariser gradient where
     reg_weight != 0), ONE launch.  dyn (device floats {reg_b, gate, ...} of the current step) replaces the host reg_b and
@@ -226,6 +237,27 @@ def adaround_backward_multi(items, reg_b=0.0, dyn=None):
     else:
         L.check(L.lib().nq_adaround_backward_multi(segs, len(items), float(reg_b), _stream()), "adaround_backward_multi")
     return outs
+
+
+def adaround_adam_multi(items, opt, reg_b=0.0, dyn=None, beta1=0.9, beta2=0.999, eps=1e-8):
+    """items: [(x, gy, alpha, delta, zp, n_levels, reg_weight)] in the order of opt.params (= the alphas): d(alpha) (+ the
+    regulariser gradient) and opt's Adam step in ONE launch; advances opt.t.  Bit-identical to adaround_backward_multi
+    followed by opt.step (tested); d(alpha) itself is not materialised."""
+    assert len(items) == len(opt.params)
+    opt.t += 1
+    segs = (L.AdaAdamSeg * len(items))()
+    keep = []
+    for i, (sg, (x, gy, alpha, delta, zp, n_levels, reg_weight)) in enumerate(zip(segs, items)):
+        x, gy, alpha, delta, zp = _dev(x), _dev(gy), _dev(alpha), _dev(delta), _dev(zp)
+        if alpha.data_ptr() != opt.params[i].data_ptr():
+            raise RuntimeError("adaround_adam_multi: items must be in the optimiser's parameter order")
+        rows, rl, per_row = _rows(x, delta)
+        keep.append((x, gy))
+        sg.x, sg.gy, sg.alpha, sg.delta, sg.zp, sg.m, sg.v = _p(x), _p(gy), _p(alpha), _p(delta), _p(zp), _p(opt.m[i]), _p(opt.v[i])
+        sg.rows, sg.row_len, sg.per_row, sg.n_levels, sg.reg_weight = rows, rl, per_row, n_levels, float(reg_weight)
+    step_size, bc2_sqrt = opt.scalars(opt.t, beta1, beta2)
+    L.check(L.lib().nq_adaround_adam_multi(segs, len(items), float(reg_b), step_size, beta1, beta2, eps, bc2_sqrt, _p(dyn),
+                                           _stream()), "adaround_adam_multi")
 
 
 class FusedAdam:
@@ -509,13 +541,39 @@ def conv_wgrad3_supported(B, cin, H, W, cout, k):
     return bool(_q("nq_conv_wgrad3_supported", B, cin, H, W, cout, k))
 
 
-def conv_wgrad3_raw(x, dy, cout, k, want_db, out=None):
+class PendingReductions:
+    """Slab reductions of several weight-gradient launches, performed by ONE nq_wgrad_reduce_multi launch at `flush()`
+    (bit-identical to the per-launch reductions; the slabs and outputs stay referenced until then)."""
+
+    def __init__(self):
+        self.segs, self.keep = [], []
+
+    def add(self, seg, *tensors):
+        self.segs.append(seg)
+        self.keep.append(tensors)
+
+    def flush(self):
+        if self.segs:
+            arr = (L.WgrSeg * len(self.segs))(*self.segs)
+            L.check(L.lib().nq_wgrad_reduce_multi(arr, len(self.segs), _stream()), "wgrad_reduce_multi")
+        self.segs, self.keep = [], []
+
+
+def conv_wgrad3_raw(x, dy, cout, k, want_db, out=None, defer=None):
     """bf16x3 counterpart of conv_wgrad_raw.  out = (dw, db) pre-allocated contiguous outputs (views of a flat
-    gradient arena) or None."""
+    gradient arena) or None.  defer (PendingReductions): only the split kernel runs now, dw / db are valid after
+    defer.flush()."""
     B, cin, H, W = x.shape
     ws = torch.empty(_q("nq_conv_wgrad3_ws_floats", B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
     dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32) if out is None else out[0]
     db = (torch.empty(cout, device=x.device, dtype=torch.float32) if out is None else out[1]) if want_db else None
+    if defer is not None:
+        seg = L.WgrSeg()
+        _timed(("conv_wgrad3", k, cin, cout, H, W, B, 0),
+               lambda: L.check(L.lib().nq_conv_wgrad3_slabs(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k,
+                                                            ctypes.byref(seg), _stream()), "conv_wgrad3_slabs"))
+        defer.add(seg, ws, dw, db)
+        return dw, db
     _timed(("conv_wgrad3", k, cin, cout, H, W, B, 0),
            lambda: L.check(L.lib().nq_conv_wgrad3(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k, _stream()),
                            "conv_wgrad3"))
@@ -531,7 +589,7 @@ def channel_sum(x):
     return out
 
 
-def conv_wgrad_swapped3(x, dy, cout, k, want_db, out=None):
+def conv_wgrad_swapped3(x, dy, cout, k, want_db, out=None, defer=None):
     """Weight gradient of a conv with very few OUTPUT channels (the 3-channel head) by swapping operand roles:
     R[ci][(co,kh,kw)] = sum_p x[ci][p] * dy[co][p + tap]  is the weight gradient of the conv  dy -> x-channels, and
     dW[co][ci][kh][kw] = R[ci][co][K-1-kh][K-1-kw].  The big tensor (x, 242 MB) is then the un-shifted GEMM operand
@@ -541,9 +599,16 @@ def conv_wgrad_swapped3(x, dy, cout, k, want_db, out=None):
     ws = torch.empty(_q("nq_conv_wgrad3_ws_floats", B, cout, H, W, cin, k), device=x.device, dtype=torch.float32)
     dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32) if out is None else out[0]
     # the slab reduction writes dW[co][ci][K-1-kh][K-1-kw] directly (no permute / flip / copy passes)
-    _timed(("conv_wgrad3", k, cout, cin, H, W, B, 0),
-           lambda: L.check(L.lib().nq_conv_wgrad3_swapped(_p(x), _p(dy), _p(dw), _p(ws), B, cin, H, W, cout, k, _stream()),
-                           "conv_wgrad3_swapped"))
+    if defer is not None:
+        seg = L.WgrSeg()
+        _timed(("conv_wgrad3", k, cout, cin, H, W, B, 0),
+               lambda: L.check(L.lib().nq_conv_wgrad3_swapped_slabs(_p(x), _p(dy), _p(dw), _p(ws), B, cin, H, W, cout, k,
+                                                                    ctypes.byref(seg), _stream()), "conv_wgrad3_swapped_slabs"))
+        defer.add(seg, ws, dw)
+    else:
+        _timed(("conv_wgrad3", k, cout, cin, H, W, B, 0),
+               lambda: L.check(L.lib().nq_conv_wgrad3_swapped(_p(x), _p(dy), _p(dw), _p(ws), B, cin, H, W, cout, k, _stream()),
+                               "conv_wgrad3_swapped"))
     db = None
     if want_db:
         db = channel_sum(dy)
@@ -553,11 +618,18 @@ def conv_wgrad_swapped3(x, dy, cout, k, want_db, out=None):
     return dw, db
 
 
-def conv_wgrad_raw(x, dy, cout, k, want_db, x_gelu=False, out=None):
+def conv_wgrad_raw(x, dy, cout, k, want_db, x_gelu=False, out=None, defer=None):
     B, cin, H, W = x.shape
     ws = torch.empty(_q("nq_conv_wgrad_ws_floats", B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
     dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32) if out is None else out[0]
     db = (torch.empty(cout, device=x.device, dtype=torch.float32) if out is None else out[1]) if want_db else None
+    if defer is not None:
+        seg = L.WgrSeg()
+        _timed(("conv_wgrad", k, cin, cout, H, W, B, 0),
+               lambda: L.check(L.lib().nq_conv_wgrad_slabs(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k,
+                                                           1 if x_gelu else 0, ctypes.byref(seg), _stream()), "conv_wgrad_slabs"))
+        defer.add(seg, ws, dw, db)
+        return dw, db
     _timed(("conv_wgrad", k, cin, cout, H, W, B, 0),
            lambda: L.check(L.lib().nq_conv_wgrad(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k,
                                                  1 if x_gelu else 0, _stream()), "conv_wgrad"))
@@ -955,23 +1027,28 @@ class _DecoderStackFn(Function):
                 off += sizes[2 * l + 1]
                 views.append((wv, bv))
 
+        # the split-K weight-gradient kernels leave slabs; their fixed-order reductions run in ONE launch per group of
+        # layers (`pending.flush()`: at the end of the backward pass, or before each part of the arena goes to the
+        # data-parallel hook) instead of one ~10 us launch per layer.  Same sums in the same order: bit-identical.
+        pending = PendingReductions() if side is None and os.environ.get("NQ_DEFER_REDUCE", "1") != "0" else None
+
         def wgrad(l, dconv):
             k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
             x_in = xs[l]
             Bx, _, Hx, Wx = x_in.shape
             out = views[l] if views is not None else None
             if spec.precision == "bf16x3" and not in_gelu and conv_wgrad3_supported(Bx, cin, Hx, Wx, cout, k):
-                return conv_wgrad3_raw(x_in, dconv, cout, k, has_b, out=out)
+                return conv_wgrad3_raw(x_in, dconv, cout, k, has_b, out=out, defer=pending)
             if spec.precision == "bf16x3" and not in_gelu and cout <= 4 and cin > 4 and cout * k * k <= 64 \
                     and conv_wgrad3_supported(Bx, cout, Hx, Wx, cin, k):
                 if l == n - 1 and has_b and head_db is not None:   # bias gradient handed over by l2_loss_head_grad
-                    dw, _ = conv_wgrad_swapped3(x_in, dconv, cout, k, False, out=out)
+                    dw, _ = conv_wgrad_swapped3(x_in, dconv, cout, k, False, out=out, defer=pending)
                     if out is not None:
                         out[1].copy_(head_db)
                         return dw, out[1]
                     return dw, head_db
-                return conv_wgrad_swapped3(x_in, dconv, cout, k, has_b, out=out)
-            return conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu, out=out)
+                return conv_wgrad_swapped3(x_in, dconv, cout, k, has_b, out=out, defer=pending)
+            return conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu, out=out, defer=pending)
 
         def dgrad(l, dconv):
             """conv-output gradient of layer l -> conv-output gradient of layer l - 1 (l >= 1)"""
@@ -1013,10 +1090,14 @@ class _DecoderStackFn(Function):
                 grads[2 * l], grads[2 * l + 1] = wgrad(l, dcs[l])
                 dcs[l] = None
             off = sum(sizes[:2 * split])
+            if pending is not None:
+                pending.flush()
             arena_hook(arena[:off], False)
             for l in range(split, n):
                 grads[2 * l], grads[2 * l + 1] = wgrad(l, dcs[l])
                 dcs[l] = None
+            if pending is not None:
+                pending.flush()
             arena_hook(arena[off:], True)
             ctx.nq_arena_reduced = True
             return (d_emb, None) + tuple(grads)
@@ -1041,6 +1122,8 @@ class _DecoderStackFn(Function):
         if side is not None:
             main.wait_stream(side)
             keep.clear()
+        if pending is not None:
+            pending.flush()
         if arena is not None:
             arena_hook(arena)
             ctx.nq_arena_reduced = True

@@ -244,7 +244,12 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                     items.append((L.src, gW, wq.alpha.data, wq.delta.data, wq.zero_point, wq.n_levels,
                                   weight if (reg_on or dyn is not None) else 0.0))
                     items.append((L.bias, gb, bq.alpha.data, bq.delta.data, bq.zero_point, bq.n_levels, 0.0))
-                grads = ops.adaround_backward_multi(items, b, dyn=dyn)
+                if probe is None and os.environ.get("NQ_FUSED_ADAM", "1") != "0":
+                    # nobody looks at d(alpha): backward of the fake-quant + regulariser gradient + Adam in ONE pass
+                    ops.adaround_adam_multi(items, opt, b, dyn=dyn)
+                    grads = None
+                else:
+                    grads = ops.adaround_backward_multi(items, b, dyn=dyn)
             else:
                 for L in layers:
                     gW, gb = L.grads()
@@ -264,7 +269,8 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                         total, float(rec), rl_f, b, count))
             if probe is not None:
                 probe('ada' if ada else 'uaq', layers, grads)
-            opt.step(grads, dyn=dyn)
+            if grads is not None:
+                opt.step(grads, dyn=dyn)
             for L in layers:
                 L.release()
 
@@ -293,7 +299,8 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
             if st is None or st['order'].shape[0] < nb or st['cur_idx'].numel() != per:
                 st = dict(order=torch.zeros((nb, per), device=device, dtype=torch.int64),
                           scal=torch.zeros((nb, 4), device=device, dtype=torch.float32),
-                          step=torch.zeros((), device=device, dtype=torch.int32),
+                          step=torch.zeros(2, device=device, dtype=torch.int32),     # {step counter, arrival ticket}
+                          emb=torch.zeros((per,) + tuple(cali_data.shape[1:]), device=device, dtype=torch.float32),
                           cur_idx=torch.zeros(per, device=device, dtype=torch.int64),
                           cur_scal=torch.zeros(4, device=device, dtype=torch.float32))
                 graph, warm = None, 0
@@ -306,8 +313,9 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
             st['step'].zero_()
 
             def static_batch():
-                ops.step_prologue(st['order'], st['scal'], st['step'], st['cur_idx'], st['cur_scal'])
-                return (gt.cache.frames, st['cur_idx']), cali_data.index_select(0, st['cur_idx'])
+                # current batch indices + scalars into their fixed slots and the batch's decoder inputs cali_data[idx], one launch
+                ops.step_prologue_gather(st['order'], st['scal'], st['step'], st['cur_idx'], st['cur_scal'], cali_data, st['emb'])
+                return (gt.cache.frames, st['cur_idx']), st['emb']
 
             for i in range(nb):
                 if step_hook is not None:

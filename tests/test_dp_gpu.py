@@ -271,7 +271,9 @@ def test_emulated_world2_arena_reduction(golden, rehearsal_env, monkeypatch, ove
     # may differ by more than 1e-3 of its largest one -- a regulariser gradient counted twice (or halved, or averaged
     # with a stale one) changes nearly ALL entries of every d(alpha) by far more: it dominates d(alpha) at b = 20.
     def frac_off(a, b):
-        return float(((a.double() - b.double()).abs() > 1e-3 * float(b.double().abs().max()) + 1e-30).double().mean())
+        """share of entries further apart than 1e-3 of the largest one (two entries of a small tensor are always allowed)"""
+        off = ((a.double() - b.double()).abs() > 1e-3 * float(b.double().abs().max()) + 1e-30).double().sum()
+        return max(float(off) - 2.0, 0.0) / a.numel()
 
     for st, phase in enumerate(single["phases"]):
         for x, y in zip(runs[0]["arena"][st], single["arena"][st]):

@@ -1001,6 +1001,88 @@ def test_head_data_gradient_streaming_kernel(ops, shape, monkeypatch):
     assert torch.equal(y_new, f())
 
 
+@pytest.mark.parametrize("arch,had", [("hnerv", False), ("nerv", True)])
+def test_deferred_slab_reductions_are_bit_identical(ops, golden, arch, had, monkeypatch):
+    """Round 3: the split-K weight-gradient kernels of all layers leave their slabs and ONE nq_wgrad_reduce_multi launch
+    per backward pass sums them (per segment the same split groups in the same order as the per-layer reduction launches
+    it replaces): every conv weight / bias gradient of the decoder is bit-identical with NQ_DEFER_REDUCE=0 and =1, also
+    under the two-phase (data-parallel) schedule, where each part of the arena is reduced before it is handed over."""
+    from neuroquant_amd.models import _decode
+    from neuroquant_amd.quantization import QuantModel
+    z = golden("decode.npz")
+    qnn = QuantModel(_build(arch, state_dict_from_npz(z, f"{arch}_sd:")), hadamard=had,
+                     weight_quant_params=dict(n_bits=8, channel_wise=True))
+    spec, provs = _decode._fused_stack(qnn.model)
+    emb = G(z[f"{arch}_emb"])
+
+    def grads(two_phase):
+        g = torch.Generator().manual_seed(4)
+        ws = [tuple(t.detach().clone().requires_grad_(True) for t in p()) for p in provs]
+        seen = []
+        with ops.grad_arena_hook((lambda part, last=True: seen.append(part.clone())) if two_phase is not None else None,
+                                 two_phase=bool(two_phase)):
+            out = ops.decoder_stack(emb, spec, ws)
+            (out * torch.randn(out.shape, generator=g).to(DEV)).sum().backward()
+        return [t.grad.clone() for pair in ws for t in pair], seen
+
+    for two_phase in (None, False, True):
+        monkeypatch.setenv("NQ_DEFER_REDUCE", "0")
+        a, seen_a = grads(two_phase)
+        monkeypatch.setenv("NQ_DEFER_REDUCE", "1")
+        b, seen_b = grads(two_phase)
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+        # what the hook SAW was already reduced (the collective must not run on un-summed slabs' outputs)
+        assert len(seen_a) == len(seen_b) and all(torch.equal(x, y) for x, y in zip(seen_a, seen_b))
+        if two_phase is not None:
+            assert torch.equal(torch.cat([s.reshape(-1) for s in seen_b]), torch.cat([t.reshape(-1) for t in b]))
+
+
+@pytest.mark.parametrize("use_dyn", [False, True])
+def test_fused_adaround_backward_adam_is_bit_identical(ops, use_dyn):
+    """nq_adaround_adam_multi (round 3: d(alpha) + regulariser gradient + Adam in one pass, d(alpha) never stored) against
+    nq_adaround_backward_multi followed by nq_adam_step_multi over three steps: alpha, m and v bit for bit, per-row and
+    scalar scales, vectorised and ragged tensors, regulariser on and gated off."""
+    g = torch.Generator().manual_seed(21)
+    shapes = [(12, 7, 3, 3), (5, 4, 1, 1), (9,), (64, 16, 5, 5), (3,)]
+    bits = [4, 6, 5, 3, 6]
+
+    def make():
+        items, params = [], []
+        gg = torch.Generator().manual_seed(22)
+        for shp, nb in zip(shapes, bits):
+            x = torch.randn(shp, generator=gg).to(DEV)
+            d, zp = ops.scale_init_max(x, 2 ** nb, True)
+            d, zp, alpha = ops.adaround_init(x, d, zp)
+            alpha = (alpha + 0.3 * torch.randn(shp, generator=gg).to(DEV)).contiguous()
+            items.append([x, None, alpha, d, zp, 2 ** nb, 0.01 if len(shp) == 4 else 0.0])
+            params.append(alpha)
+        return items, params
+
+    a_items, a_par = make()
+    b_items, b_par = make()
+    opt_a, opt_b = ops.FusedAdam(a_par, lr=0.003), ops.FusedAdam(b_par, lr=0.003)
+    for step in range(3):
+        gate = 0.0 if step == 1 else 1.0
+        reg_b = 20.0 - 3.0 * step
+        gys = [torch.randn(x[0].shape, generator=g).to(DEV) * 1e-3 for x in a_items]
+        dyn = None
+        if use_dyn:
+            s1, s2 = opt_a.scalars(opt_a.t + 1)
+            dyn = torch.tensor([reg_b, gate, s1, s2], dtype=torch.float32, device=DEV)
+        rw = (lambda w: w) if use_dyn else (lambda w: w * gate)      # host path: the caller gates the weight itself
+        # separate
+        grads = ops.adaround_backward_multi([(x, gy, al, d, zp, nl, rw(w)) for (x, _, al, d, zp, nl, w), gy in zip(a_items, gys)],
+                                            reg_b, dyn=dyn)
+        opt_a.step(grads, dyn=dyn)
+        # fused
+        ops.adaround_adam_multi([(x, gy, al, d, zp, nl, rw(w)) for (x, _, al, d, zp, nl, w), gy in zip(b_items, gys)], opt_b,
+                                reg_b, dyn=dyn)
+        assert opt_a.t == opt_b.t == step + 1
+        for pa, pb, ma, mb, va, vb in zip(a_par, b_par, opt_a.m, opt_b.m, opt_a.v, opt_b.v):
+            assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert not torch.equal(a_par[0], make()[1][0])      # the parameters did move
+
+
 def test_two_interleaved_decoders_keep_their_own_state(ops, golden):
     """The in-process hand-offs live on the decoder's own autograd node (round 3): the fused loss tail's
     head gradient / bias gradient (img.grad_fn.nq_head), the data-parallel arena hook captured at forward time
