@@ -12,6 +12,8 @@ int nq_conv3_nst_k3();
 int nq_conv3_nst_k5();
 int nq_conv3_nst8_k3();
 int nq_conv3_nst8_k5();
+int nq_conv3_nstk_k3(int);
+int nq_conv3_nstk_k5(int);
 int nq_conv_wgrad3_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int nq_conv_wgrad3_k5(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 }
@@ -40,12 +42,18 @@ inline int pick_mi3(int Cout) {
   return best;
 }
 inline int nst_of(int k) { return k == 5 ? nq_conv3_nst_k5() : nq_conv3_nst_k3(); }
-inline int nst8_of(int k) { return k == 5 ? nq_conv3_nst8_k5() : nq_conv3_nst8_k3(); }
-// the last 16-channel chunk holds <= 8 channels -> it is laid out (and run) as (1 octet x 4 taps) k-steps, see Conv3Args::tail8
-inline bool tail8_of(int Cin) { return Cin - CC * ((Cin + CC - 1) / CC - 1) <= 8; }
-inline int64_t total_steps3(int Cin, int k) {
+inline int nstk_of(int k, int kind) { return k == 5 ? nq_conv3_nstk_k5(kind) : nq_conv3_nstk_k3(kind); }
+// shape of the last 16-channel chunk by the channels r it really holds (Conv3Args::tail): 1: r <= 4, 2: r <= 8, 3: r <= 12,
+// 0: a full chunk -- it is laid out (and run) with fewer, denser k-steps
+// (the half-octet kinds only on tiles of <= 64 channels: conv_igemm3_impl.h, nq_conv3_tail_kind)
+inline int tail_kind_of(int Cin, int mi) {
+  const int r = Cin - CC * ((Cin + CC - 1) / CC - 1);
+  if (mi >= 5) return r <= 8 ? 2 : 0;
+  return r <= 4 ? 1 : (r <= 8 ? 2 : (r <= 12 ? 3 : 0));
+}
+inline int64_t total_steps3(int Cin, int k, int mi) {
   const int nchunk = (Cin + CC - 1) / CC;
-  return tail8_of(Cin) ? (int64_t)(nchunk - 1) * nst_of(k) + nst8_of(k) : (int64_t)nchunk * nst_of(k);
+  return (int64_t)(nchunk - 1) * nst_of(k) + nstk_of(k, tail_kind_of(Cin, mi));
 }
 
 // Operand of the bf16x3 kernels: 16-byte fragment slots [global k-step][plane hi/lo][co tile][kq][MT] of 8 bf16 k-values.
@@ -54,17 +62,32 @@ inline int64_t total_steps3(int Cin, int k) {
 struct WL3 {
   const float* w;
   uint4* out;
-  int Cin, Cout, KK, NST, NST8, nchunk, tail8, co_tiles, MT, transposed;
+  int Cin, Cout, KK, NST, NSTT, nchunk, tail, co_tiles, MT, transposed;   // tail: kind of the last chunk, NSTT its k-steps
   int co16;        // 16-channel groups of output channels: ceil(co_tiles*MT / 16)
   int64_t slots;
 };
 // k-value e (0..7) of lane group kq at k-step s of a chunk -> (channel within the chunk, tap); tap >= KK: zero weight.
-//   full chunk : 2 octets x 2 taps per step   ch = (kq&1)*8 + e, tap = 2s + (kq>>1)
-//   tail8 chunk: 1 octet x 4 taps per step    ch = e,            tap = 4s + kq          (Conv3Args::tail8)
-__device__ __forceinline__ void wl3_elem(bool t8, int s, int kq, int e, int& ch, int& tap) {
-  if (t8) {
+// (mirrors the B-fragment assembly of conv_igemm3_kernel, Conv3Args::tail)
+//   0 full chunk : 2 octets x 2 taps per step          ch = (kq&1)*8 + e, tap = 2s + (kq>>1)
+//   2 <= 8 ch    : 1 octet x 4 taps per step           ch = e,            tap = 4s + kq
+//   1 <= 4 ch    : slot j = 4s + kq = 4 channels x taps (2j, 2j+1)        ch = e & 3, tap = 2j + (e >> 2)
+//   3 <= 12 ch   : slots j < KK: octet 0 at tap j; slots KK + h: channels 8..11 x taps (2h, 2h+1)
+__device__ __forceinline__ void wl3_elem(int kind, int KK, int s, int kq, int e, int& ch, int& tap) {
+  const int j = 4 * s + kq;
+  if (kind == 2) {
     ch = e;
-    tap = 4 * s + kq;
+    tap = j;
+  } else if (kind == 1) {
+    ch = e & 3;
+    tap = 2 * j + (e >> 2);
+  } else if (kind == 3) {
+    if (j < KK) {
+      ch = e;
+      tap = j;
+    } else {
+      ch = 8 + (e & 3);
+      tap = 2 * (j - KK) + (e >> 2);
+    }
   } else {
     ch = (kq & 1) * 8 + e;
     tap = 2 * s + (kq >> 1);
@@ -80,10 +103,10 @@ constexpr int WL3_KKMAX = 25;
 __device__ __forceinline__ void wl3_tile(const WL3& p, int c, int g16, float* __restrict__ T /* [16][16*KK (+1)] */) {
   const int KK = p.KK, RS = 16 * KK + 1;   // row stride: odd -> the 16 rows of a column land in different banks
   const int tid = threadIdx.x;
-  const int nfull = p.nchunk - p.tail8;
-  const bool t8 = p.tail8 && c == nfull;
-  const int nst = t8 ? p.NST8 : p.NST;
-  const int64_t gs0 = t8 ? (int64_t)nfull * p.NST : (int64_t)c * p.NST;
+  const int nfull = p.nchunk - (p.tail ? 1 : 0);
+  const int kind = (c == nfull) ? p.tail : 0;
+  const int nst = kind ? p.NSTT : p.NST;
+  const int64_t gs0 = (int64_t)c * p.NST;   // every chunk in front of c is a full one
   // rows a = 0..15, columns (b, tap): forward a = co (g16*16 + a), b = ch (c*16 + b); transposed a = ch, b = co
   const int Ra = p.transposed ? p.Cin : p.Cout;            // valid extent of the row index (stored tensor's dim 0)
   const int Cb = p.transposed ? p.Cout : p.Cin;            // stored tensor's dim 1
@@ -109,7 +132,7 @@ __device__ __forceinline__ void wl3_tile(const WL3& p, int c, int g16, float* __
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         int ch, tap;
-        wl3_elem(t8, st, kq, 2 * j + t, ch, tap);
+        wl3_elem(kind, KK, st, kq, 2 * j + t, ch, tap);
         float x = 0.f;
         if (tap < KK) x = p.transposed ? T[ch * RS + col * KK + (KK - 1 - tap)] : T[col * RS + ch * KK + tap];
         v[t] = x;
@@ -362,7 +385,7 @@ int64_t nq_conv3_weight_bytes(int Cin, int Cout, int k) {
   const int mi = pick_mi3(Cout), mt = 16 * mi;
   const int64_t co_tiles = (Cout + mt - 1) / mt, nchunk = (Cin + CC - 1) / CC;
   (void)nchunk;
-  return total_steps3(Cin, k) * 2 * co_tiles * 4 * mt * 16;
+  return total_steps3(Cin, k, mi) * 2 * co_tiles * 4 * mt * 16;
 }
 
 // w: OIHW weight tensor of the STORED conv (Cout_w, Cin_w, k, k).  transposed = 0 -> operand of the forward conv
@@ -371,10 +394,9 @@ static bool wl3_fill(WL3& p, const float* w, void* wt3, int Cin, int Cout, int k
   if (!w || !wt3 || !(k == 3 || k == 5) || Cin <= 0 || Cout <= 0) return false;
   const int mi = pick_mi3(Cout);
   p.w = w; p.out = reinterpret_cast<uint4*>(wt3);
-  p.Cin = Cin; p.Cout = Cout; p.KK = k * k; p.NST = nst_of(k); p.NST8 = nst8_of(k);
+  p.Cin = Cin; p.Cout = Cout; p.KK = k * k; p.NST = nst_of(k); p.tail = tail_kind_of(Cin, mi); p.NSTT = nstk_of(k, p.tail);
   p.MT = 16 * mi; p.co_tiles = (Cout + p.MT - 1) / p.MT; p.nchunk = (Cin + CC - 1) / CC; p.transposed = transposed;
-  p.tail8 = tail8_of(Cin) ? 1 : 0;
-  p.slots = total_steps3(Cin, k) * p.co_tiles * 4 * p.MT;
+  p.slots = total_steps3(Cin, k, mi) * p.co_tiles * 4 * p.MT;
   p.co16 = (p.co_tiles * p.MT + 15) / 16;
   return true;
 }

@@ -50,8 +50,12 @@ struct Conv3Args {
   float* slab;            // [nsplit][B][Cout][H][W] raw partial sums when nsplit > 1 (nq_conv_splitk_finish adds them)
   int lds_epi;            // the launch reserved MT*1024 B of LDS: the data-gradient epilogue may transpose through it
   unsigned w_bytes;       // size of the wt3 operand (buffer resource range)
-  int tail8;              // the LAST channel chunk holds <= 8 channels: it runs NST8 k-steps of (1 octet x 4 taps) instead of
-                          // NST steps of (2 octets x 2 taps) -- 7 instead of 13 steps for k = 5 (no MFMAs on an all-zero octet)
+  int tail;               // shape of the LAST 16-channel chunk, by the channels r it really holds (no MFMAs on all-zero k-values):
+                          //   0: r > 12   NST   k-steps of (2 octets x 2 taps)                                  13 for k = 5
+                          //   3: r <= 12  NST12 steps: octet 0 as (1 octet x 1 tap) slots, the half octet 1 as
+                          //               (4 channels x 2 taps) slots, 4 slots per step                          10
+                          //   2: r <= 8   NST8  steps of (1 octet x 4 taps)                                       7
+                          //   1: r <= 4   NST4  steps of (4 channels x 8 taps)                                    4
 };
 
 // Timing experiments only (never in the product build): -DNQ_IG3_ABL=n compiles the kernel WITHOUT one of its parts
@@ -80,6 +84,17 @@ constexpr int NPIX = PH * PW;
 constexpr int PP = (NPIX + 15) / 16 * 16;  // octet-plane stride in pixels (16-byte units): multiple of 256 B
 constexpr int NST = (KK + 1) / 2;          // k-steps per channel chunk
 constexpr int NST8 = (KK + 3) / 4;         // k-steps of a tail chunk of <= 8 channels (lane group kq -> tap 4*step + kq)
+constexpr int NHALF = (KK + 1) / 2;        // (4 channels x 2 taps) slots of a half octet
+constexpr int NST4 = (NHALF + 3) / 4;      // k-steps of a tail chunk of <= 4 channels
+constexpr int NST12 = (KK + NHALF + 3) / 4;  // k-steps of a tail chunk of 9..12 channels
+constexpr int nst_of_kind(int kind) { return kind == 1 ? NST4 : (kind == 2 ? NST8 : (kind == 3 ? NST12 : NST)); }
+// kind of the last 16-channel chunk (Conv3Args::tail) for Cin input channels on the 16*mi-channel tile; shared with
+// nq_weight_layout3 (conv3.hip), which must lay the operand out the same way
+static inline int nq_conv3_tail_kind(int Cin, int mi) {
+  const int r = Cin - 16 * ((Cin + 15) / 16 - 1);
+  if (mi >= 5) return r <= 8 ? 2 : 0;
+  return r <= 4 ? 1 : (r <= 8 ? 2 : (r <= 12 ? 3 : 0));
+}
 constexpr int CC = 16;                     // channels per chunk
 constexpr int PATCH_U4 = 2 * 2 * PP;       // 16-byte units per patch buffer: [plane][octet][PP]
 constexpr int NITEM = 2 * NPIX;            // staging items (octet, pixel)
@@ -232,9 +247,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // ---- prologue: step 0 -> LDS buffer 0 (via set A), step 1 in flight in set B ----
   const int nchunk = min(a.per_split, a.nchunk - c_lo);
-  const bool tail = a.tail8 && (c_lo + nchunk == a.nchunk);   // this split ends with the short tail chunk
+  const int tail = (c_lo + nchunk == a.nchunk) ? a.tail : 0;   // this split ends with a short tail chunk of that kind
   const int nfull = nchunk - (tail ? 1 : 0);
-  const int G = nfull * NST + (tail ? NST8 : 0);
+  const int G = nfull * NST + (tail == 1 ? NST4 : (tail == 2 ? NST8 : (tail == 3 ? NST12 : 0)));
   const int Gm1 = G - 1;
   // per-thread byte offsets of its weight units within one k-step (fixed): unit f = tid + i*256 of [plane][kq][MT]; a
   // thread without an item in the last round loads unit 0 (valid memory, never stored)
@@ -277,8 +292,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // one chunk; PAR = parity of its first global step
   auto run_chunk = [&](auto par_c, auto tail_c, int ch) {
     constexpr int PAR = decltype(par_c)::value;
-    constexpr bool TAIL = decltype(tail_c)::value != 0;
-    constexpr int NSTC = TAIL ? NST8 : NST;
+    constexpr int TK = decltype(tail_c)::value;   // tail kind (Conv3Args::tail), 0 = full chunk
+    constexpr bool TAIL = TK != 0;
+    constexpr int NSTC = nst_of_kind(TK);
     const int g0 = ch * NST;   // every chunk in front of this one is a full chunk
     steps3<0, NSTC>([&](auto st_c) {
       constexpr int st = decltype(st_c)::value;
@@ -301,6 +317,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           if (NQ_IG3_ABL != 8 && NQ_IG3_ABL != 10 && (NQ_IG3_SPREAD ? (j * LS) / 8 : LS - 1) == st) NQ3_LOAD_PATCH_J(ch + 1, j)
         }
       }
+      bf16x8 bh[4], bl[4];
+      if constexpr (TK == 1 || TK == 3) {
+        // slots with HALF octets: a lane group's 8 k-values are (4 channels x tap A, 4 channels x tap B) = the low 8 bytes
+        // of two patch units; a whole-octet slot of a 12-channel tail is the two halves of ONE unit.  All B fragments of
+        // such a chunk are two 8-byte LDS reads at per-lane-group offsets (in 8-byte units, relative to the lane's pixel).
+        constexpr auto tapoff = [](int tap) { return (tap < KK ? tap : KK - 1) / KS * PW + (tap < KK ? tap : KK - 1) % KS; };
+        constexpr auto off0 = [tapoff](int j) {   // first 8 bytes of slot j
+          if (TK == 1) return 2 * tapoff(2 * j);
+          return j < KK ? 2 * tapoff(j) : 2 * (PP + tapoff(2 * (j - KK)));
+        };
+        constexpr auto off1 = [tapoff](int j) {   // second 8 bytes of slot j
+          if (TK == 1) return 2 * tapoff(2 * j + 1);
+          return j < KK ? 2 * tapoff(j) + 1 : 2 * (PP + tapoff(2 * (j - KK) + 1));
+        };
+        constexpr int j0 = 4 * st;
+        constexpr int a0 = off0(j0), a1 = off0(j0 + 1), a2 = off0(j0 + 2), a3 = off0(j0 + 3);
+        constexpr int b0 = off1(j0), b1 = off1(j0 + 1), b2 = off1(j0 + 2), b3 = off1(j0 + 3);
+        const int o0 = (kq == 0) ? a0 : (kq == 1) ? a1 : (kq == 2) ? a2 : a3;
+        const int o1 = (kq == 0) ? b0 : (kq == 1) ? b1 : (kq == 2) ? b2 : b3;
+        const uint2* __restrict__ p2 = reinterpret_cast<const uint2*>(patch0) + 2 * ((2 * wave) * PW + l16);
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+          const int o = 2 * ((nb >> 1) * PW + (nb & 1) * 16);
+          const uint2 h0 = p2[o0 + o], h1 = p2[o1 + o];
+          const uint2 l0 = p2[4 * PP + o0 + o], l1 = p2[4 * PP + o1 + o];   // lo plane: 2 * PP units of 16 bytes further
+          bh[nb] = __builtin_bit_cast(bf16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
+          bl[nb] = __builtin_bit_cast(bf16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
+        }
+      } else {
       const u32x4* __restrict__ pbt;
       if constexpr (TAIL) {
         // one octet, four taps: lane group kq -> tap 4*st + kq (clamped; its weights are zero when padded)
@@ -317,14 +362,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr int off_e = (te / KS) * PW + (te % KS), off_o = (to_ / KS) * PW + (to_ % KS);
         pbt = pb + (odd_tap ? off_o : off_e);
       }
-      const u32x4* __restrict__ wb = wl0 + (g & WMASK) * W_U4 + a_lane;
-      bf16x8 bh[4], bl[4];
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
         const int o = (NQ_IG3_ABL == 6) ? 0 : (nb >> 1) * PW + (nb & 1) * 16;   // ablation 6: one fragment pair for all four
         bh[nb] = __builtin_bit_cast(bf16x8, pbt[o]);
         bl[nb] = __builtin_bit_cast(bf16x8, pbt[2 * PP + o]);
       }
+      }
+      const u32x4* __restrict__ wb = wl0 + (g & WMASK) * W_U4 + a_lane;
       bf16x8 ah0 = __builtin_bit_cast(bf16x8, wb[0]), al0 = __builtin_bit_cast(bf16x8, wb[4 * MT]);
       steps3<0, MI>([&](auto mi_c) {
         constexpr int mi = decltype(mi_c)::value;
@@ -397,8 +442,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (ch + 1 < nfull) run_chunk(std::integral_constant<int, (NST & 1)>{}, C0{}, ch + 1);
   }
   if (tail) {   // parity of its first global step = parity of nfull * NST
-    if ((nfull & 1) && (NST & 1)) run_chunk(C1{}, C1{}, nfull);
-    else run_chunk(C0{}, C1{}, nfull);
+    const bool odd = ((nfull & NST) & 1) != 0;
+    using K1 = std::integral_constant<int, 1>;
+    using K2 = std::integral_constant<int, 2>;
+    using K3 = std::integral_constant<int, 3>;
+    // the half-octet kinds exist for MI <= 4 only (nq_conv3_tail_kind): on the 80-channel tile, already at 256 VGPRs, their
+    // two per-lane-group offsets spilled into the K loop (dec5 forward 387 -> 476 us)
+    if constexpr (MI <= 4) {
+      if (tail == 1) {
+        if (odd) run_chunk(C1{}, K1{}, nfull);
+        else run_chunk(C0{}, K1{}, nfull);
+      } else if (tail == 3) {
+        if (odd) run_chunk(C1{}, K3{}, nfull);
+        else run_chunk(C0{}, K3{}, nfull);
+      }
+    }
+    if (tail == 2) {
+      if (odd) run_chunk(C1{}, K2{}, nfull);
+      else run_chunk(C0{}, K2{}, nfull);
+    }
   }
 #undef NQ3_LOAD_PATCH
 #undef NQ3_STORE_PATCH
@@ -648,9 +710,9 @@ extern "C" int NQ_CAT(nq_conv_igemm3_k, NQ_KS)(const float* x, const void* wt3, 
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.r = r; a.epi = epi;
   a.tiles_x = (W + TW - 1) / TW;
   a.nchunk = (Cin + CC - 1) / CC;
-  a.tail8 = (Cin - CC * (a.nchunk - 1)) <= 8 ? 1 : 0;
+  a.tail = nq_conv3_tail_kind(Cin, mi_sel);
   a.co_tiles = (Cout + 16 * mi_sel - 1) / (16 * mi_sel);
-  a.w_bytes = (unsigned)(((int64_t)(a.nchunk - 1) * NST + (a.tail8 ? NST8 : NST)) * 2 * a.co_tiles * 4 * (16 * mi_sel) * 16);
+  a.w_bytes = (unsigned)(((int64_t)(a.nchunk - 1) * NST + nst_of_kind(a.tail)) * 2 * a.co_tiles * 4 * (16 * mi_sel) * 16);
   const int tiles = a.tiles_x * ((H + TH - 1) / TH);
   switch (mi_sel) {
     case 1: return launch_igemm3<1>(a, tiles, st);
@@ -665,3 +727,4 @@ extern "C" int NQ_CAT(nq_conv_igemm3_k, NQ_KS)(const float* x, const void* wt3, 
 // steps per chunk for this kernel size (used by nq_weight_layout3)
 extern "C" int NQ_CAT(nq_conv3_nst_k, NQ_KS)() { return NST; }
 extern "C" int NQ_CAT(nq_conv3_nst8_k, NQ_KS)() { return NST8; }
+extern "C" int NQ_CAT(nq_conv3_nstk_k, NQ_KS)(int kind) { return nst_of_kind(kind); }
