@@ -21,6 +21,7 @@ Prints ONE JSON line (rank 0) with
                   bound (mfma | hbm) is chosen per kernel from its arithmetic intensity against the ridge of its matrix pipe;
   `repeats`       it/s of `--repeats` independent timed runs of the same K steps (`value` = the first);
   `fp32`          the same workload re-timed with exact-fp32 MFMA convolutions (NQ_CONV_PRECISION=fp32) and its roofline;
+  `phase1`        the same workload's PHASE-1 iteration (scale learning, 5 % of a run) timed the same way;
   `nerv`          BASELINE configs[2] (NeRV Bunny_1280x640_3M + Hadamard) timed the same way, with its own roofline object;
   `psnr`          BASELINE configs[0] (the first 8 Bunny frames at 640x1280, iters_w = 50) on the committed trained
                   checkpoint: final PSNR of the CPU oracle, the GPU with exact fp32 and with bf16x3 (bar: within 0.02 dB);
@@ -148,6 +149,7 @@ def main():
     ap.add_argument("--no-fp32", action="store_true", help="skip the exact-fp32 re-timing")
     ap.add_argument("--fp32-steps", type=int, default=20)
     ap.add_argument("--repeats", type=int, default=3, help="timed runs of K steps; value = the first, all go into `repeats`")
+    ap.add_argument("--no-phase1", action="store_true", help="skip the phase-1 (scale learning) timing")
     ap.add_argument("--no-nerv", action="store_true", help="skip the NeRV-3M + Hadamard object (BASELINE configs[2])")
     ap.add_argument("--workload", choices=("hnerv", "nerv"), default="hnerv",
                     help="hnerv = the headline config (default); nerv = NeRV-3M + Hadamard (BASELINE configs[2]), no cpu baseline")
@@ -191,8 +193,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed_run(precision, K, W, workload=args.workload):
-        """Fresh QuantModel on the seeded weights; W untimed + K timed phase-2 iterations under `precision`."""
+    def timed_run(precision, K, W, workload=args.workload, phase1=False):
+        """Fresh QuantModel on the seeded weights; W untimed + K timed phase-2 iterations under `precision` (phase1: the
+        same count of PHASE-1 iterations -- scales learned through the UAQ fake-quant, reference calib_model.py:119-165)."""
         nerv = workload == "nerv"
         ops.set_conv_precision(precision)
         model = build_model(workload=workload).to(dev)
@@ -230,7 +233,9 @@ def main():
                 t["t1"] = time.perf_counter()
                 t["prof"] = ops.profile_stop() if not os.environ.get("NQ_BENCH_NOPROF") else {}
 
-        model_reconstruction(qnn, cali_data=emb, gt=loader, arch=workload, batch_size=gB, iters=len(loader),
+        # iters = 20 * len(loader): int(0.05 * iters / len) = 1 phase-1 epoch of W+K+1 iterations, cut after W+K by max_steps
+        model_reconstruction(qnn, cali_data=emb, gt=loader, arch=workload, batch_size=gB,
+                             iters=(20 if phase1 else 1) * len(loader),
                              hadamard=nerv, warmup=0.0, max_steps=steps_total, step_hook=hook, **FLAGS)
         if "t1" not in t:
             hook(steps_total)
@@ -254,6 +259,8 @@ def main():
     if not args.no_fp32:
         Kf = max(1, min(K, args.fp32_steps))
         fp32_run = (timed_run("fp32", Kf, W), Kf)
+    # phase 1 (5 % of a run: 990 of the 20 988 iterations) timed the same way
+    p1_run = timed_run("bf16x3", K, W, phase1=True) if not args.no_phase1 else None
     # BASELINE configs[2] (NeRV Bunny_1280x640_3M + Hadamard) as a measured object of the same line
     nerv_run = None
     if not nerv and not args.no_nerv:
@@ -330,6 +337,10 @@ def main():
         "repeats": {"values": [round(K * per_step_units / r["elapsed"], 3) for r in [main_run] + more_runs],
                     "note": "it/s of independent timed runs of the same K steps on this box; `value` is the first"},
         "fp32": fp32,
+        "phase1": None if p1_run is None else {
+            "value": round(K * per_step_units / p1_run["elapsed"], 3), "ms_per_step": round(p1_run["elapsed"] / K * 1e3, 3),
+            "steps": K, "note": "phase-1 iterations (UAQ fake-quant, d(delta), Adam on the scales) of the same workload; a 21k "
+                                "run is 990 of these + 19 998 phase-2 iterations (`value`)"},
         "nerv": nerv_obj,
         "psnr": psnr,
         "cpu_baseline": cpu,

@@ -132,6 +132,12 @@ typedef struct nq_ada_adam_seg {
 int nq_adaround_adam_multi(const nq_ada_adam_seg* segs, int nseg, float reg_b, float step_size, float beta1, float beta2, float eps,
                            float bc2_sqrt, const float* dyn, nq_stream_t stream);
 int nq_adaround_forward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream);
+/* The UAQ fake-quant (nq_uaq_forward) / its d(delta) (nq_uaq_backward without dx) for several tensors in one launch:
+ * phase 1 of the calibration (calib_model.py:119-165).  Uses x, gy (backward), delta, zp, out (forward: y; backward:
+ * d(delta), one value per reduction row), rows, row_len, per_row, n_levels of nq_ada_seg; alpha / soft / reg_weight are
+ * ignored.  Bit-identical to the single-tensor entry points. */
+int nq_uaq_forward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream);
+int nq_uaq_backward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream);
 int nq_adaround_backward_multi(const nq_ada_seg* segs, int nseg, float reg_b, nq_stream_t stream);
 int nq_adam_step_multi(const nq_adam_seg* segs, int nseg, float step_size, float beta1, float beta2, float eps,
                        float bc2_sqrt, nq_stream_t stream);

@@ -87,6 +87,8 @@ def _load():
     sig("nq_adaround_backward", I, P, P, P, P, P, P, L, L, I, I, F, F, P)
     sig("nq_adaround_adam_multi", I, POINTER(AdaAdamSeg), I, F, F, F, F, F, F, P, P)
     sig("nq_adaround_forward_multi", I, POINTER(AdaSeg), I, P)
+    sig("nq_uaq_forward_multi", I, POINTER(AdaSeg), I, P)
+    sig("nq_uaq_backward_multi", I, POINTER(AdaSeg), I, P)
     sig("nq_adaround_backward_multi", I, POINTER(AdaSeg), I, F, P)
     sig("nq_adam_step_multi", I, POINTER(AdamSeg), I, F, F, F, F, F, P)
     sig("nq_step_prologue", I, P, P, P, P, P, I, I, P)
@@ -134,7 +136,7 @@ def _load():
 EXPORTS = (
     "nq_abi_version", "nq_error_string", "nq_scale_init_max", "nq_uaq_forward", "nq_uaq_backward",
     "nq_adaround_init", "nq_adaround_forward", "nq_adaround_backward", "nq_reduce_ws_floats", "nq_round_loss", "nq_round_loss_backward",
-    "nq_adam_step", "nq_adaround_adam_multi", "nq_adaround_forward_multi", "nq_adaround_backward_multi", "nq_adam_step_multi", "nq_step_prologue", "nq_step_prologue_gather", "nq_adaround_backward_multi_dyn", "nq_adam_step_multi_dyn", "nq_fwht", "nq_fwht_multi", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
+    "nq_adam_step", "nq_adaround_adam_multi", "nq_adaround_forward_multi", "nq_uaq_forward_multi", "nq_uaq_backward_multi", "nq_adaround_backward_multi", "nq_adam_step_multi", "nq_step_prologue", "nq_step_prologue_gather", "nq_adaround_backward_multi_dyn", "nq_adam_step_multi_dyn", "nq_fwht", "nq_fwht_multi", "nq_weight_layouts", "nq_conv_operand_dims", "nq_conv_forward_ws_floats", "nq_conv_forward",
     "nq_conv3_supported", "nq_conv3_weight_bytes", "nq_weight_layout3", "nq_weight_layout3_multi", "nq_weight_layouts_multi", "nq_conv_forward3_ws_floats", "nq_conv_forward3",
     "nq_conv_wgrad3_supported", "nq_conv_wgrad3_ws_floats", "nq_conv_wgrad3_plan", "nq_conv_wgrad3", "nq_conv_wgrad3_swapped",
     "nq_conv_wgrad3_slabs", "nq_conv_wgrad3_swapped_slabs", "nq_conv_wgrad_slabs", "nq_wgrad_reduce_multi",

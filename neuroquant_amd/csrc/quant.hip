@@ -474,6 +474,59 @@ __global__ __launch_bounds__(TPB) void adaround_adam_multi_kernel(AdaAdamMulti t
   }
 }
 
+// UAQ fake-quant of several tensors in ONE launch (phase 1 of the calibration, calib_model.py:119-165): the forward is the
+// per-element arithmetic of uaq_fwd_kernel, the backward one workgroup per reduction row with uaq_bwd_kernel's loop and
+// block sum -- bit-identical to the single-tensor launches.
+struct UaqSegD {
+  const float* x;
+  const float* gy;      // backward
+  const float* delta;
+  const float* zp;
+  float* out;           // forward: y; backward: d(delta)
+  int64_t n;            // forward: elements
+  int64_t rows;         // backward: reduction rows
+  int row_len, per_row;
+  float qmax;
+};
+struct UaqMulti {
+  UaqSegD s[MAXSEG];
+  int blk0[MAXSEG + 1];
+  int nseg;
+};
+__global__ __launch_bounds__(TPB) void uaq_fwd_multi_kernel(UaqMulti t) {
+  const int k = find_seg(t, blockIdx.x);
+  const UaqSegD& sg = t.s[k];
+  int64_t i = (int64_t)(blockIdx.x - t.blk0[k]) * (TPB * EPT) + threadIdx.x;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e, i += TPB) {
+    if (i < sg.n) {
+      const int64_t row = sg.per_row ? i / sg.row_len : 0;
+      const float d = sg.delta[row], z = sg.zp[row];
+      float xi = rintf(sg.x[i] / d) + z;
+      float xq = fminf(fmaxf(xi, 0.f), sg.qmax);
+      sg.out[i] = (xq - z) * d;
+    }
+  }
+}
+__global__ __launch_bounds__(TPB) void uaq_bwd_multi_kernel(UaqMulti t) {
+  __shared__ float red[16];
+  const int k = find_seg(t, blockIdx.x);
+  const UaqSegD& sg = t.s[k];
+  const int64_t row = blockIdx.x - t.blk0[k];
+  const float d = sg.delta[row], z = sg.zp[row];
+  const int64_t base = row * sg.row_len;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < sg.row_len; i += TPB) {
+    float u = sg.x[base + i] / d;
+    float xi = rintf(u) + z;
+    float xq = fminf(fmaxf(xi, 0.f), sg.qmax);
+    float inside = (xi >= 0.f && xi <= sg.qmax) ? 1.f : 0.f;
+    acc += sg.gy[base + i] * ((xq - z) - inside * u);
+  }
+  float s = nq_block_sum(acc, red);
+  if (threadIdx.x == 0) sg.out[row] = s;
+}
+
 inline unsigned blocks_per_row(int64_t row_len) { return (unsigned)((row_len + TPB * EPT - 1) / (TPB * EPT)); }
 inline dim3 row_grid(int64_t rows, int64_t row_len) { return dim3((unsigned)(rows * blocks_per_row(row_len)), 1, 1); }
 // rows x blocks-per-row must fit grid.x (2^31 - 1); any channel count a decoder can have does
@@ -522,6 +575,39 @@ int nq_uaq_backward(const float* x, const float* gy, const float* delta, const f
                      per_row, (float)(n_levels - 1));
   return nq_launch_status();
 }
+
+static int uaq_multi(const nq_ada_seg* segs, int nseg, bool bwd, nq_stream_t stream) {
+  if (!segs || nseg <= 0) return NQ_ERR_INVALID;
+  for (int base = 0; base < nseg; base += MAXSEG) {
+    UaqMulti t;
+    t.nseg = (nseg - base < MAXSEG) ? nseg - base : MAXSEG;
+    int64_t blocks = 0;
+    for (int k = 0; k < t.nseg; ++k) {
+      const nq_ada_seg& h = segs[base + k];
+      if (!h.x || !h.delta || !h.zp || !h.out || (bwd && !h.gy) || h.rows <= 0 || h.row_len <= 0) return NQ_ERR_INVALID;
+      UaqSegD& d = t.s[k];
+      d.x = h.x; d.gy = h.gy; d.delta = h.delta; d.zp = h.zp; d.out = h.out;
+      d.n = h.rows * h.row_len;
+      // per_row = 0: the whole tensor is one reduction row with one scale
+      d.rows = h.per_row ? h.rows : 1;
+      const int64_t rl = h.per_row ? h.row_len : h.rows * h.row_len;
+      if (rl > 0x7fffffffLL) return NQ_ERR_INVALID;
+      d.row_len = (int)rl; d.per_row = h.per_row; d.qmax = (float)(h.n_levels - 1);
+      t.blk0[k] = (int)blocks;
+      blocks += bwd ? d.rows : (d.n + TPB * EPT - 1) / (TPB * EPT);
+      if (blocks > 0x7fffffffLL) return NQ_ERR_INVALID;
+    }
+    t.blk0[t.nseg] = (int)blocks;
+    if (bwd)
+      hipLaunchKernelGGL(uaq_bwd_multi_kernel, dim3((unsigned)blocks), dim3(TPB), 0, nq_s(stream), t);
+    else
+      hipLaunchKernelGGL(uaq_fwd_multi_kernel, dim3((unsigned)blocks), dim3(TPB), 0, nq_s(stream), t);
+  }
+  return nq_launch_status();
+}
+
+int nq_uaq_forward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream) { return uaq_multi(segs, nseg, false, stream); }
+int nq_uaq_backward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream) { return uaq_multi(segs, nseg, true, stream); }
 
 int nq_adaround_init(const float* x, const float* delta_in, const float* zp_in, float* delta_out, float* zp_out,
                      float* alpha, int64_t rows, int64_t row_len, int per_row, nq_stream_t stream) {

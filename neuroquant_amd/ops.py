@@ -202,6 +202,37 @@ def adaround_forward_multi(items):
     return outs
 
 
+def uaq_forward_multi(items):
+    """items: [(x, delta, zp, n_levels)] -> [UAQ fake-quantised tensors], ONE launch (same arithmetic as uaq_forward)."""
+    segs = (L.AdaSeg * len(items))()
+    outs = []
+    for sg, (x, delta, zp, n_levels) in zip(segs, items):
+        x, delta, zp = _dev(x), _dev(delta), _dev(zp)
+        rows, rl, per_row = _rows(x, delta)
+        y = torch.empty_like(x)
+        outs.append(y)
+        sg.x, sg.gy, sg.alpha, sg.delta, sg.zp, sg.out = _p(x), None, None, _p(delta), _p(zp), _p(y)
+        sg.rows, sg.row_len, sg.per_row, sg.n_levels, sg.soft, sg.reg_weight = rows, rl, per_row, n_levels, 0, 0.0
+    L.check(L.lib().nq_uaq_forward_multi(segs, len(items), _stream()), "uaq_forward_multi")
+    return outs
+
+
+def uaq_backward_multi(items):
+    """items: [(x, gy, delta, zp, n_levels)] -> [d(delta)], ONE launch (same arithmetic and summation order as uaq_backward)."""
+    segs = (L.AdaSeg * len(items))()
+    outs, keep = [], []
+    for sg, (x, gy, delta, zp, n_levels) in zip(segs, items):
+        x, gy, delta, zp = _dev(x), _dev(gy), _dev(delta), _dev(zp)
+        rows, rl, per_row = _rows(x, delta)
+        dd = torch.empty_like(delta)
+        outs.append(dd)
+        keep.append((x, gy))
+        sg.x, sg.gy, sg.alpha, sg.delta, sg.zp, sg.out = _p(x), _p(gy), None, _p(delta), _p(zp), _p(dd)
+        sg.rows, sg.row_len, sg.per_row, sg.n_levels, sg.soft, sg.reg_weight = rows, rl, per_row, n_levels, 0, 0.0
+    L.check(L.lib().nq_uaq_backward_multi(segs, len(items), _stream()), "uaq_backward_multi")
+    return outs
+
+
 def step_prologue(order_tab, scal_tab, step_ctr, cur_idx, cur_scal):
     """nq_step_prologue: cur_idx <- order_tab[*step], cur_scal <- scal_tab[*step], *step += 1 (captured iterations)."""
     L.check(L.lib().nq_step_prologue(_p(order_tab), _p(scal_tab), _p(step_ctr), _p(cur_idx), _p(cur_scal), cur_idx.numel(),

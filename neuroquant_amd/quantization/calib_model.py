@@ -107,6 +107,10 @@ class _Layer:
         self._finish(Wq, ops.adaround_forward(self.bias, bq.alpha.data, bq.delta.data, bq.zero_point, bq.n_levels,
                                               bq.soft_targets))
 
+    def uaq_items(self):
+        wq, bq = self.m.weight_quantizer, self.m.bias_quantizer
+        return [(self.src, wq.delta.data, wq.zero_point, wq.n_levels), (self.bias, bq.delta.data, bq.zero_point, bq.n_levels)]
+
     def ada_items(self):
         wq, bq = self.m.weight_quantizer, self.m.bias_quantizer
         return [(self.src, wq.alpha.data, wq.delta.data, wq.zero_point, wq.n_levels, wq.soft_targets),
@@ -214,9 +218,15 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                 else:
                     for i, L in enumerate(layers):
                         L._finish(fq[2 * i], fq[2 * i + 1])
-            else:
-                for L in layers:
-                    L.forward_uaq()
+            else:   # phase 1: the UAQ fake-quant of all 14 tensors in one launch (+ one FWHT launch with Hadamard)
+                fq = ops.uaq_forward_multi([it for L in layers for it in L.uaq_items()])
+                if hadamard:
+                    had = ops.fwht_channels_multi([(fq[2 * i], L.n, L.c_in) for i, L in enumerate(layers)])
+                    for i, L in enumerate(layers):
+                        L._finish(had[i], fq[2 * i + 1], transformed=True)
+                else:
+                    for i, L in enumerate(layers):
+                        L._finish(fq[2 * i], fq[2 * i + 1])
             img_out, _, _ = model(inputs)
             # lp_loss p=2 (quantizer.py:66-71) and its gradient; behind a tanh-headed fused decoder the loss kernel also
             # applies the tanh backward and sums the head's bias gradient (ops.l2_loss_head_grad), reading the target
@@ -250,12 +260,15 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                     grads = None
                 else:
                     grads = ops.adaround_backward_multi(items, b, dyn=dyn)
-            else:
-                for L in layers:
-                    gW, gb = L.grads()
+            else:   # d(delta) of all 14 tensors in one launch
+                gWs = ops.fwht_channels_multi([(L.W.grad, L.n, L.n) for L in layers]) if hadamard else None
+                items = []
+                for i, L in enumerate(layers):
+                    gW, gb = (gWs[i], L.b.grad) if hadamard else L.grads()
                     wq, bq = L.m.weight_quantizer, L.m.bias_quantizer
-                    grads.append(ops.uaq_backward(L.src, gW, wq.delta.data, wq.zero_point, wq.n_levels))
-                    grads.append(ops.uaq_backward(L.bias, gb, bq.delta.data, bq.zero_point, bq.n_levels))
+                    items.append((L.src, gW, wq.delta.data, wq.zero_point, wq.n_levels))
+                    items.append((L.bias, gb, bq.delta.data, bq.zero_point, bq.n_levels))
+                grads = ops.uaq_backward_multi(items)
             if want_log:
                 rl = torch.zeros((), device=device)
                 if reg_on:

@@ -1083,6 +1083,29 @@ def test_fused_adaround_backward_adam_is_bit_identical(ops, use_dyn):
     assert not torch.equal(a_par[0], make()[1][0])      # the parameters did move
 
 
+def test_uaq_multi_tensor_launches_are_bit_identical(ops):
+    """nq_uaq_forward_multi / nq_uaq_backward_multi (round 3: phase 1 in two launches instead of 28) against the
+    single-tensor entry points: per-row and scalar scales, 4-D weights and 1-D biases, ragged sizes."""
+    g = torch.Generator().manual_seed(31)
+    shapes = [(12, 7, 3, 3), (5, 4, 1, 1), (9,), (64, 16, 5, 5), (3,), (130, 3, 1, 1)]
+    bits = [4, 6, 5, 3, 6, 8]
+    fwd, bwd = [], []
+    for shp, nb in zip(shapes, bits):
+        x = torch.randn(shp, generator=g).to(DEV)
+        d, zp = ops.scale_init_max(x, 2 ** nb, True)
+        d = d * (1 + 0.05 * torch.rand(d.shape, generator=g).to(DEV))       # scales away from their initial values
+        gy = torch.randn(shp, generator=g).to(DEV)
+        fwd.append((x, d, zp, 2 ** nb))
+        bwd.append((x, gy, d, zp, 2 ** nb))
+    ys = ops.uaq_forward_multi(fwd)
+    dds = ops.uaq_backward_multi(bwd)
+    for (x, d, zp, nl), y in zip(fwd, ys):
+        assert torch.equal(y, ops.uaq_forward(x, d, zp, nl))
+    for (x, gy, d, zp, nl), dd in zip(bwd, dds):
+        ref = ops.uaq_backward(x, gy, d, zp, nl)
+        assert dd.shape == d.shape and torch.equal(dd.reshape(-1), ref.reshape(-1))
+
+
 def test_two_interleaved_decoders_keep_their_own_state(ops, golden):
     """The in-process hand-offs live on the decoder's own autograd node (round 3): the fused loss tail's
     head gradient / bias gradient (img.grad_fn.nq_head), the data-parallel arena hook captured at forward time

@@ -4,7 +4,7 @@ grep "seed 90" gpurun_out/r03_gate21k_b.log
 python -m pytest tests/test_dp_gpu.py tests/test_hip_parity.py tests/test_full_size.py -x -q -m gpu -k "dp_gpu or interleaved or fused_loss or arena or single_step or 2_and_4" > gpurun_out/t_r3a.log 2>&1
 tail -5 gpurun_out/t_r3a.log
 R=$PWD; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_a -- python3 $R/bench.py --steps 12 --warmup 5 --frames 8 --no-cpu-baseline --no-fp32 --no-nerv --repeats 1 > $R/gpurun_out/trace_a.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_a -- python3 $R/bench.py --steps 12 --warmup 5 --frames 8 --no-cpu-baseline --no-fp32 --no-nerv --no-phase1 --repeats 1 > $R/gpurun_out/trace_a.log 2>&1
 cd $R
 python3 tools/trace_step.py gpurun_out/trace_a gpurun_out/r03_a_step_sequence.txt > /dev/null; tail -3 gpurun_out/r03_a_step_sequence.txt
 rm -rf gpurun_out/trace_a

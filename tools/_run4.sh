@@ -8,7 +8,7 @@ import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg', d['value'], d['ms_per_step'], d['repeats']['values'])"
 done
 R=$PWD; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_b -- python3 $R/bench.py --steps 12 --warmup 5 --frames 8 --no-cpu-baseline --no-fp32 --no-nerv --repeats 1 > $R/gpurun_out/trace_b.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/trace_b -- python3 $R/bench.py --steps 12 --warmup 5 --frames 8 --no-cpu-baseline --no-fp32 --no-nerv --no-phase1 --repeats 1 > $R/gpurun_out/trace_b.log 2>&1
 cd $R
 python3 tools/trace_step.py gpurun_out/trace_b gpurun_out/r03_b_step_sequence.txt > /dev/null; tail -3 gpurun_out/r03_b_step_sequence.txt
 rm -rf gpurun_out/trace_b

@@ -4,11 +4,12 @@
 # summaries go to profiles/<tag>_* via profiles/summarize.py.  Output is kept under gpurun_out/ (merged back by gpurun).
 set -e
 TAG=${1:-rXX}
+WL=${2:-hnerv}          # hnerv (the headline workload) | nerv (BASELINE configs[2]: NeRV-3M + Hadamard)
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --frames 8 --no-cpu-baseline --no-fp32"
+BENCH="python3 $R/bench.py --frames 8 --workload $WL --no-cpu-baseline --no-fp32 --no-nerv --no-phase1 --repeats 1"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH --steps 40 --warmup 6 > $OUT/stats.log 2>&1
 export NQ_GRAPH=0
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/fetch -- $BENCH --steps 3 --warmup 1 > $OUT/fetch.log 2>&1
@@ -21,5 +22,10 @@ python3 profiles/summarize.py $OUT/stats $OUT/fetch $OUT/write $OUT/sq $OUT/$TAG
 cp $(ls $OUT/stats/*/*_kernel_stats.csv | head -1) $OUT/${TAG}_rocprof_kernel_stats_raw.csv
 grep '^{' $OUT/stats.log | tail -1
 cat $OUT/summary.log
+# one steady-state iteration kernel by kernel (graph replay), from a trace of its own
+cd /tmp
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- $BENCH --steps 12 --warmup 5 > $OUT/trace.log 2>&1
+cd $R
+python3 tools/trace_step.py $OUT/trace $OUT/${TAG}_step_sequence.txt > /dev/null 2>&1 || true
 # keep the merge-back small: the raw traces are not needed once summarised
-rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/sq
+rm -rf $OUT/stats $OUT/fetch $OUT/write $OUT/sq $OUT/trace
