@@ -100,8 +100,11 @@ __device__ __forceinline__ void wl3_elem(int kind, int KK, int s, int kq, int e,
 // per thread, 256 contiguous bytes per 16 lanes.  (Round 2's kernel gathered the 8 values of a slot straight from global
 // memory at a stride of KK or Cout*KK floats: 22.6 us for the layers of HNeRV-3M, most of it uncoalesced reads.)
 constexpr int WL3_KKMAX = 25;
+// (KK is a template parameter: the index arithmetic -- e / (16*KK), rem / KK per loaded float, eight (channel, tap) pairs per
+// slot -- was most of the kernel's time with a run-time divisor)
+template <int KK>
 __device__ __forceinline__ void wl3_tile(const WL3& p, int c, int g16, float* __restrict__ T /* [16][16*KK (+1)] */) {
-  const int KK = p.KK, RS = 16 * KK + 1;   // row stride: odd -> the 16 rows of a column land in different banks
+  constexpr int RS = 16 * KK + 1;   // row stride: odd -> the 16 rows of a column land in different banks
   const int tid = threadIdx.x;
   const int nfull = p.nchunk - (p.tail ? 1 : 0);
   const int kind = (c == nfull) ? p.tail : 0;
@@ -151,7 +154,8 @@ __device__ __forceinline__ void wl3_tile(const WL3& p, int c, int g16, float* __
 
 __global__ __launch_bounds__(256) void weight_layout3_kernel(WL3 p) {
   __shared__ float T[16 * (16 * WL3_KKMAX + 1)];
-  wl3_tile(p, (int)blockIdx.x / p.co16, (int)blockIdx.x % p.co16, T);
+  if (p.KK == 25) wl3_tile<25>(p, (int)blockIdx.x / p.co16, (int)blockIdx.x % p.co16, T);
+  else wl3_tile<9>(p, (int)blockIdx.x / p.co16, (int)blockIdx.x % p.co16, T);
 }
 
 // all layers' operands (forward and data-gradient) in ONE launch: the table travels as a kernel argument
@@ -166,7 +170,8 @@ __global__ __launch_bounds__(256) void weight_layout3_multi_kernel(WL3Multi t) {
   int k = 0;
   while (k + 1 < t.nseg && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
   const int blk = (int)blockIdx.x - t.blk0[k];
-  wl3_tile(t.s[k], blk / t.s[k].co16, blk % t.s[k].co16, T);
+  if (t.s[k].KK == 25) wl3_tile<25>(t.s[k], blk / t.s[k].co16, blk % t.s[k].co16, T);
+  else wl3_tile<9>(t.s[k], blk / t.s[k].co16, blk % t.s[k].co16, T);
 }
 
 // split-K of the forward / data-gradient kernel over 16-channel chunks when the pixel x channel grid alone cannot fill

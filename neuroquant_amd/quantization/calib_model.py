@@ -195,8 +195,13 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
     # are launched EAGERLY between their replays (asynchronous, on RCCL's stream): the collectives never sit inside a
     # captured region, the ~1.2 ms of host work per eager iteration becomes three graph launches + two collective
     # enqueues.  The decoder then runs without autograd (ops.decoder_forward_manual / decoder_backward_steps: the same
-    # code as the autograd node, driven stage by stage).  NQ_DP_GRAPH=0 keeps data-parallel iterations eager.
-    dp_graph = use_graph and dp and os.environ.get("NQ_DP_GRAPH", "1") != "0"
+    # code as the autograd node, driven stage by stage).  Opt-in (NQ_DP_GRAPH=1): on one MI355X with a 1-rank RCCL group the
+    # headline workload is GPU-bound either way (HNeRV-3M: 435.5 it/s eager, 1.30 ms of host work per 2.30 ms step, vs 432.8
+    # captured), while NeRV-3M + Hadamard is host-bound when eager (648 -> 883 it/s captured); and a capture next to a live
+    # process group has one more failure mode than eager launches (RCCL's watchdog thread polls its events: the captures
+    # below therefore use the thread-local capture mode), so the driver's multi-GPU runs keep the path proven in round 2
+    # unless asked otherwise.
+    dp_graph = use_graph and dp and os.environ.get("NQ_DP_GRAPH", "0") == "1"
     if dp and not dp_graph:
         use_graph = False
     fused_stack = None
@@ -214,14 +219,17 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
         cap = torch.cuda.Stream()
         cap.wait_stream(torch.cuda.current_stream())
         torch.cuda.synchronize()
+        # thread-local capture mode: every launch of the staged body comes from THIS thread (no autograd worker), and the
+        # process group's watchdog thread must stay free to query its events while we capture (in the default global mode
+        # its hipEventQuery aborts the process: "operation not permitted when stream is capturing")
         with torch.cuda.stream(cap):
-            graphs[0].capture_begin(pool=pool)
+            graphs[0].capture_begin(pool=pool, capture_error_mode="thread_local")
 
             def cut(k, part):
                 graphs[-1].capture_end()
                 parts.append(part)
                 graphs.append(torch.cuda.CUDAGraph())
-                graphs[-1].capture_begin(pool=pool)
+                graphs[-1].capture_begin(pool=pool, capture_error_mode="thread_local")
 
             run_body(cut)
             graphs[-1].capture_end()
@@ -312,6 +320,19 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
             if dp and staged is None and not ops.arena_reduced(img_out):
                 # generic path (decoder not fused into one node): flatten, all-reduce, un-flatten
                 allreduce_mean_([t.grad for L in layers for t in (L.W, L.b)])
+            # (the logged rounding loss is the forward value: alpha BEFORE this iteration's update -- the fused kernel below
+            # updates alpha in place)
+            if want_log:
+                rl = torch.zeros((), device=device)
+                if reg_on:
+                    for L in layers:
+                        ops.round_loss(L.m.weight_quantizer.alpha.data, b, weight, out=rl, accumulate=True)
+                total, rl_f = float(rec) + float(rl), float(rl)
+                if recorder is not None:
+                    recorder.append((total, rl_f, float(b), count))
+                if count % 500 == 0:
+                    logging.info('Total loss:\t{:.4f} (rec:{:.4f}, round:{:.4f})\tb={:.2f}\tcount={}'.format(
+                        total, float(rec), rl_f, b, count))
             grads = []
             if ada:   # d(alpha) of all 14 tensors (+ regulariser gradient on the weights) in one launch
                 items = []
@@ -339,17 +360,6 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                     items.append((L.src, gW, wq.delta.data, wq.zero_point, wq.n_levels))
                     items.append((L.bias, gb, bq.delta.data, bq.zero_point, bq.n_levels))
                 grads = ops.uaq_backward_multi(items)
-            if want_log:
-                rl = torch.zeros((), device=device)
-                if reg_on:
-                    for L in layers:
-                        ops.round_loss(L.m.weight_quantizer.alpha.data, b, weight, out=rl, accumulate=True)
-                total, rl_f = float(rec) + float(rl), float(rl)
-                if recorder is not None:
-                    recorder.append((total, rl_f, float(b), count))
-                if count % 500 == 0:
-                    logging.info('Total loss:\t{:.4f} (rec:{:.4f}, round:{:.4f})\tb={:.2f}\tcount={}'.format(
-                        total, float(rec), rl_f, b, count))
             if probe is not None:
                 probe('ada' if ada else 'uaq', layers, grads)
             if grads is not None:

@@ -356,7 +356,7 @@ def test_captured_dp_iterations_equal_eager(golden, rehearsal_env, monkeypatch):
             [q.delta.detach().clone() for m in qnn.quant_modules() for q in (m.weight_quantizer, m.bias_quantizer)]
 
     monkeypatch.delenv("NQ_DP_REHEARSAL")
-    plain = run("1")                                   # no process group: the single captured graph
+    plain = run("0")                                   # no process group: the single captured graph
     monkeypatch.setenv("NQ_DP_REHEARSAL", "1")
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     calls = []
