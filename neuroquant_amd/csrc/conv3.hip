@@ -263,7 +263,9 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
     const int nseg_pc = (W / 128) * H * B;
     if (nseg_pc / 256 >= 8) {
       p.pc = 4;
-      p.nsplit = 256;
+      // NQ_WGRAD3_HEAD_SPLITS (timing runs): 256 = one 8-wave workgroup per CU (round 2), 512 = two
+      static const int hs = [] { const char* e = std::getenv("NQ_WGRAD3_HEAD_SPLITS"); return e ? atoi(e) : 512; }();
+      p.nsplit = (nseg_pc / hs >= 8) ? hs : 256;
     }
   }
   return p;

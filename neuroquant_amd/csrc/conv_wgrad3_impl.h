@@ -377,7 +377,8 @@ constexpr int ni3_for(int mi) { return mi <= 3 ? 6 : (mi <= 4 ? 6 : 6); }
 // standing in front of them in one in-order stream.  Same LDS images, same arithmetic, same slab layout as above: results
 // are bit-identical for an equal split plan.  One barrier per segment, executed by all eight waves.
 template <int MI, int NI, int SS, int SY>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wgrad3p_kernel(Wgrad3Args a) {
+// (the narrow streaming variant, NI == 1: few registers, latency-bound -> up to two workgroups per CU, conv3.hip plan_wgrad3)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NI == 1 ? 4 : 2, NI == 1 ? 4 : 2))) void conv_wgrad3p_kernel(Wgrad3Args a) {
   // A staged segment = SY image rows x 32*SS pixels = SS*SY MFMA k-steps of 32 pixels, one barrier each.
   //   SY > 1 (rows): the KS-row x halo is shared -- KS+SY-1 rows are staged for SY row-steps instead of KS per step
   //   (SY = 4: 2 rows per step instead of 5, the producers' x work and the x traffic drop by 60 %);
