@@ -100,10 +100,8 @@ inline WgradPlan plan_wgrad(int B, int Cin, int H, int W, int Cout, int k) {
   // one full wave of workgroups: 256 CUs x 2 resident workgroups (the kernels sit at 170-230 VGPRs), no ragged tail
   int ns = 512 / tiles;
   if (ns > nseg) ns = nseg;
-  // every split writes a whole co_pad x n_pad slab: with only a few segments per split the slab traffic IS the kernel
-  // (HNeRV-3M dec2, 77 -> 1024 at 10x20: 20 segments, 16 splits x 3.1 MB written and read back for 1.25 segments of
-  // work each) -> at least 4 segments per split
-  if (ns > nseg / 4) ns = nseg / 4;
+  // (fewer, longer splits for problems with few segments -- HNeRV-3M dec2: 20 segments, 16 splits x 3.1 MB of slab -- were
+  // tried: the reduction got 5 us shorter and the kernel 8 us longer)
   if (ns > 256) ns = 256;
   if (ns < 1) ns = 1;
   p.nsplit = ns;

@@ -114,6 +114,7 @@ __device__ __forceinline__ void wl3_tile(const WL3& p, int c, int g16, float* __
   const int Ra = p.transposed ? p.Cin : p.Cout;            // valid extent of the row index (stored tensor's dim 0)
   const int Cb = p.transposed ? p.Cout : p.Cin;            // stored tensor's dim 1
   const int a0 = p.transposed ? c * 16 : g16 * 16, b0 = p.transposed ? g16 * 16 : c * 16;
+#pragma unroll 5
   for (int e = tid; e < 16 * 16 * KK; e += 256) {
     const int a = e / (16 * KK), rem = e - a * (16 * KK);
     const int bb = rem / KK;

@@ -16,6 +16,7 @@ import sys
 MAP = {
     "conv_wgrad3_k5_44_148": ("conv_wgrad3p_kernel<5, 6, 1, 4>", None),
     "conv_igemm3_k5_44_148": ("conv_igemm3_kernel<5>", 819200),
+    "conv_igemm3_k3_24_96": ("conv_igemm3_kernel<3>", 819200),
     "conv_igemm3_k5_148_44": ("conv_igemm3_kernel<3>", 409600),
     "conv_wgrad3_k5_53_176": ("conv_wgrad3p_kernel<4, 7, 1, 4>", None),
     "conv_igemm3_k5_53_176": ("conv_igemm3_kernel<4>", 307200),
