@@ -23,6 +23,7 @@
 //
 // Roofline: MFMA bf16 (2.5 PFLOP/s dense, 3 MFMA flops per algorithmic flop -> 833 TFLOP/s fp32-equivalent);
 // algorithmic flops = 2*Cout*Cin*KS^2*H*W*B.
+#include <cstdlib>
 #include <type_traits>
 
 #include "nq_common.h"
@@ -68,6 +69,9 @@ struct Conv3Args {
 #endif
 #ifndef NQ_IG3_R4MIN
 #define NQ_IG3_R4MIN 5   // smallest MI that keeps its weights in a ring of four LDS buffers (one barrier per two k-steps)
+#endif
+#ifndef NQ_IG3_OCC3_DEFAULT
+#define NQ_IG3_OCC3_DEFAULT 40
 #endif
 #ifndef NQ_IG3_SPREAD
 #define NQ_IG3_SPREAD 1
@@ -120,8 +124,13 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
   }
 }
 
-template <int MI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_igemm3_kernel(Conv3Args a) {
+// WPE = waves per SIMD the register allocation aims at: 2 for the long K loops (the MFMA-bound layers: a third wave only
+// queues for the same matrix pipe and its registers are better spent on prefetch depth), 3 for the 16-/32-channel tiles
+// on short K loops (the data gradients of NeRV's last blocks, 96 -> 24 channels: <= 30 k-steps between a prologue and an
+// epilogue of global-memory latency -- bound by latency, not by issue slots: 104 -> 91 us at 320x640, tools/bench_nerv_tail.py).
+// The 48-channel tile does not fit 168 registers (264 B of scratch: 132 -> 202 us) and stays at 2.
+template <int MI, int WPE = 2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void conv_igemm3_kernel(Conv3Args a) {
   constexpr int MT = 16 * MI;
   constexpr int W_U4 = 2 * 4 * MT;            // 16-byte units per weight buffer: [plane][kq][MT]
   constexpr int WPT = (W_U4 + 255) / 256;     // per thread
@@ -689,8 +698,18 @@ int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
     a.lds_epi = 1;
     if (lds < (size_t)MT * 1024) lds = (size_t)MT * 1024;
   }
-  if (int rc = nq_lds_optin<&conv_igemm3_kernel<MI>>(lds)) return rc;
   a.tiles = tiles;
+  if constexpr (MI <= 2) {
+    // short K loop -> the three-waves-per-SIMD build (NQ_IG3_OCC3_STEPS: largest k-step count that takes it; 0 = never)
+    static const int occ3_steps = [] { const char* e = getenv("NQ_IG3_OCC3_STEPS"); return e ? atoi(e) : NQ_IG3_OCC3_DEFAULT; }();
+    const int ksteps = (a.nsplit > 1 ? a.per_split : a.nchunk - 1) * NST + (a.nsplit > 1 ? 0 : nst_of_kind(a.tail));
+    if (ksteps <= occ3_steps) {
+      if (int rc = nq_lds_optin<&conv_igemm3_kernel<MI, 3>>(lds)) return rc;
+      hipLaunchKernelGGL((conv_igemm3_kernel<MI, 3>), dim3((unsigned)(tiles * a.co_tiles * a.B * a.nsplit)), dim3(256), lds, st, a);
+      return nq_launch_status();
+    }
+  }
+  if (int rc = nq_lds_optin<&conv_igemm3_kernel<MI>>(lds)) return rc;
   hipLaunchKernelGGL(conv_igemm3_kernel<MI>, dim3((unsigned)(tiles * a.co_tiles * a.B * a.nsplit)), dim3(256), lds, st, a);
   return nq_launch_status();
 }
