@@ -35,7 +35,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from bench import BITS, HNERV_3M  # noqa: E402
+from bench import BITS, HNERV_3M, NERV_3M  # noqa: E402
 
 FLAGS = dict(weight=0.01, b_range=(20, 2), warmup=0.2, lr=0.003)
 
@@ -76,14 +76,15 @@ def load_fixture_checkpoint(name, dev):
     return model.to(dev).eval(), torch.from_numpy(z["emb"].astype(np.float32)).to(dev), float(z["fp_psnr_trainer"])
 
 
-def train_checkpoint(frames_u8, steps, dev, seed=903, lr=1e-3, log=print):
-    """FP32 fit of HNeRV-3M on `frames_u8` through the repo's trainer path (methods/regress.py: fused HIP decoder node,
-    encoder + Adam in PyTorch).  -> (model in eval mode on dev, embeddings (n,16,2,4), FP PSNR)."""
+def train_checkpoint(frames_u8, steps, dev, seed=903, lr=1e-3, log=print, arch="hnerv"):
+    """FP32 fit of HNeRV-3M (arch "nerv": NeRV-3M, input = frame index / n) on `frames_u8` through the repo's trainer path
+    (methods/regress.py: fused HIP decoder node, encoder + Adam in PyTorch).  -> (model in eval mode on dev, embeddings
+    (n,16,2,4) / (n,160,1,1), FP PSNR)."""
     from neuroquant_amd import ops
-    from neuroquant_amd.models import HNeRV
+    from neuroquant_amd.models import HNeRV, NeRV
     from neuroquant_amd.utils import CacheLoader, FrameCache
     torch.manual_seed(seed)
-    model = HNeRV(HNERV_3M).to(dev)
+    model = (HNeRV(HNERV_3M) if arch == "hnerv" else NeRV(NERV_3M)).to(dev)
     cache = FrameCache(frames_u8)
     n = len(cache)
     B = 2
@@ -100,7 +101,7 @@ def train_checkpoint(frames_u8, steps, dev, seed=903, lr=1e-3, log=print):
             for gr in opt.param_groups:
                 gr["lr"] = cur
             img = sample["img"]
-            out, _, _ = model(img)
+            out, _, _ = model(img if arch == "hnerv" else sample["idx"].to(dev).float() / n)
             loss = ops.l2_loss(out, img) / img.shape[1]
             opt.zero_grad(set_to_none=True)
             loss.backward()
@@ -112,7 +113,8 @@ def train_checkpoint(frames_u8, steps, dev, seed=903, lr=1e-3, log=print):
     model.eval()
     with torch.no_grad():
         idx = torch.arange(n, device=dev)
-        emb = torch.cat([model.encode(cache.batch(idx[i:i + 1])) for i in range(n)])
+        emb = torch.cat([model.encode(cache.batch(idx[i:i + 1])) for i in range(n)]) if arch == "hnerv" \
+            else model.encode(idx.float() / n)
         psnr = float(torch.cat([ops.frame_psnr(model.decode(emb[i:i + 1])[0], cache.batch(idx[i:i + 1]))
                                 for i in range(n)]).mean())
     log(f"FP32 fit: {steps} steps in {time.time() - t0:.1f}s, FP PSNR {psnr:.3f} dB")
@@ -132,7 +134,7 @@ def eval_psnr(qnn, emb, frames, precision="fp32"):
         ops.set_conv_precision(prev)
 
 
-def calibrate_gpu(model, frames_u8, emb, order, iters, precision, record=True, flags=FLAGS, bits=BITS):
+def calibrate_gpu(model, frames_u8, emb, order, iters, precision, record=True, flags=FLAGS, bits=BITS, arch="hnerv"):
     """One calibration of a deep copy of `model` under `precision`.  -> dict(psnr..., log (iters,4) or None, qnn)."""
     from neuroquant_amd import ops
     from neuroquant_amd.quantization import QuantModel, model_reconstruction
@@ -140,7 +142,8 @@ def calibrate_gpu(model, frames_u8, emb, order, iters, precision, record=True, f
     frames = frames_u8.float() / 255.0
     ops.set_conv_precision(precision)
     try:
-        qnn = QuantModel(copy.deepcopy(model), hadamard=False,
+        had = arch == "nerv"   # the reference calibrates NeRV with --hadamard (BASELINE configs[2])
+        qnn = QuantModel(copy.deepcopy(model), hadamard=had,
                          weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
         qnn.set_bitwidth(bits)
         qnn.eval()
@@ -152,8 +155,8 @@ def calibrate_gpu(model, frames_u8, emb, order, iters, precision, record=True, f
         loader = CacheLoader(FrameCache(frames_u8), list(range(frames_u8.shape[0])), order.shape[2], order=order)
         torch.cuda.synchronize()
         t0 = time.time()
-        model_reconstruction(qnn, cali_data=emb, gt=loader, arch="hnerv", batch_size=order.shape[2], iters=iters,
-                             hadamard=False, recorder=rec, **flags)
+        model_reconstruction(qnn, cali_data=emb, gt=loader, arch=arch, batch_size=order.shape[2], iters=iters,
+                             hadamard=had, recorder=rec, **flags)
         torch.cuda.synchronize()
         res["seconds"] = time.time() - t0
         qnn.set_quant_state(True)
@@ -218,12 +221,12 @@ def run(args, log=print):
         model = model.to(dev).eval()
         emb, fp_psnr = blob["emb"].to(dev), blob["fp_psnr"]
     else:
-        model, emb, fp_psnr = train_checkpoint(frames_u8, args.train_steps, dev, log=log)
+        model, emb, fp_psnr = train_checkpoint(frames_u8, args.train_steps, dev, log=log, arch=args.arch)
         if args.save_ckpt:
             os.makedirs(os.path.dirname(os.path.abspath(args.save_ckpt)), exist_ok=True)
             torch.save({"sd": {k: v.cpu() for k, v in model.state_dict().items()}, "emb": emb.cpu(), "fp_psnr": fp_psnr},
                        args.save_ckpt)
-    res = {"config": f"HNeRV Bunny_1280x640_3M, {n} frames ({args.frames}), B={B}, bits {BITS}, iters_w={args.iters}",
+    res = {"config": f"{'HNeRV' if args.arch == 'hnerv' else 'NeRV + Hadamard'} Bunny_1280x640_3M, {n} frames ({args.frames}), B={B}, bits {BITS}, iters_w={args.iters}",
            "fp_psnr": fp_psnr, "train_steps": args.train_steps}
 
     # ---- fp32 MFMA vs bf16x3, same recorded order, phase 1 + phase 2 ----
@@ -240,7 +243,7 @@ def run(args, log=print):
         swapped = np.ascontiguousarray(order[..., ::-1])
         for tag, prec, od in (("fp32", "fp32", order), ("fp32_swapped", "fp32", swapped),
                               ("bf16x3", "bf16x3", order), ("bf16x3_swapped", "bf16x3", swapped)):
-            r, lg, qnn = calibrate_gpu(model, frames_u8, emb, od, args.iters, prec, record=args.record)
+            r, lg, qnn = calibrate_gpu(model, frames_u8, emb, od, args.iters, prec, record=args.record, arch=args.arch)
             row[tag] = r
             keep[tag] = (lg, qnn)
             log(f"seed {sd_} {tag}: {r['seconds']:.1f}s, PSNR w/o opt {r['q_noopt']:.4f} -> w/ opt {r['q_opt']:.4f} dB")
@@ -262,6 +265,7 @@ def run(args, log=print):
 
     # ---- GPU exact fp32 vs the CPU oracle ----
     if args.oracle_iters:
+        assert args.arch == "hnerv", "the oracle leg of this tool is wired for HNeRV (--oracle-iters 0 with --arch nerv)"
         it_o = args.oracle_iters
         assert int(0.05 * it_o / (n // B)) >= 1, "choose --oracle-iters so that phase 1 runs (int(0.05*iters/len(gt)) >= 1)"
         order_o = make_order(n, B, it_o, seed=904)
@@ -331,6 +335,7 @@ def gate_ok(res):
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--arch", choices=("hnerv", "nerv"), default="hnerv", help="nerv: NeRV-3M calibrated with the Hadamard transform")
     ap.add_argument("--train-steps", type=int, default=3000)
     ap.add_argument("--iters", type=int, default=2000, help="iters_w of the fp32-vs-bf16x3 calibration (21000 = full length)")
     ap.add_argument("--oracle-iters", type=int, default=200, help="iters_w of the GPU-vs-CPU-oracle calibration; 0 = skip")
