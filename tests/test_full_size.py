@@ -129,7 +129,9 @@ def _cmp(name, a, b, tol, mask=None, report=None):
 # (arch, hadamard, batch): BASELINE configs[1] and configs[2] at the bench's per-GPU batch of 2, and configs[3]'s GLOBAL
 # batch of 16 on one GPU (grid sizes, split plans and 32-bit buffer offsets at 1.9 GB tensors: the dec5 data gradient's
 # input is 16 x 148 x 320 x 640 x 4 B = 1.94 GB, just below the 2 GiB where signed offsets would wrap)
-@pytest.mark.parametrize("arch,had,B", [("hnerv", False, 2), ("nerv", True, 2), ("hnerv", False, 16)])
+# ("hnerv", True, 2): the reference also calibrates HNeRV with --hadamard (34.96 -> 37.19 dB); its C_in are not
+# powers of two (92, 77, 53, 44, 37: zero-padded to 128 / 64)
+@pytest.mark.parametrize("arch,had,B", [("hnerv", False, 2), ("nerv", True, 2), ("hnerv", False, 16), ("hnerv", True, 2)])
 def test_full_size_single_step_gradients(arch, had, B):
     model, sd, frames_u8, emb = _setup(arch, B)
     frames = frames_u8.float() / 255.0
