@@ -160,12 +160,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    # before the first call that initialises HIP/HSA (the runtime reads its environment once): dmabuf IPC for RCCL
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
     use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("NQ_DP_REHEARSAL"))
     if use_dist:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
     from neuroquant_amd import ops
