@@ -263,6 +263,10 @@ def main():
     # the same K timed steps again (fresh model, same warm-up): the spread the 47 ms timed region has on this box goes into
     # the line (`repeats`); `value` stays the first, contract run
     more_runs = [timed_run("bf16x3", K, W) for _ in range(max(args.repeats - 1, 0))]
+    # the secondary objects (exact fp32, phase 1, NeRV) describe the single-GPU kernels: N = 1 only -- at N > 1 the line is
+    # the data-parallel headline and its repeats, nothing else rides on the collectives
+    if world > 1:
+        args.no_fp32 = args.no_phase1 = args.no_nerv = True
     fp32_run = None
     if not args.no_fp32:
         Kf = max(1, min(K, args.fp32_steps))
