@@ -245,6 +245,9 @@ def main():
         if "t1" not in t:
             hook(steps_total)
         ops.set_conv_precision(None)
+        if os.environ.get("NQ_BENCH_DUMP_PROF") and t.get("prof"):   # debugging: per-kernel averages of every timed run
+            print("prof", workload, precision, sorted(((k[0], k[2], k[3], round(ms / c * 1e3, 1)) for k, (c, ms) in t["prof"].items()),
+                                                      key=lambda r: -r[3])[:12], file=sys.stderr)
         if "log" in t:
             print("steplog", workload, "phase1" if phase1 else "phase2", precision,
                   [(d, round((b - a) * 1e3, 2)) for (_, a), (d, b) in zip(t["log"], t["log"][1:])], file=sys.stderr)

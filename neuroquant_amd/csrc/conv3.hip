@@ -45,10 +45,8 @@ inline int nst_of(int k) { return k == 5 ? nq_conv3_nst_k5() : nq_conv3_nst_k3()
 inline int nstk_of(int k, int kind) { return k == 5 ? nq_conv3_nstk_k5(kind) : nq_conv3_nstk_k3(kind); }
 // shape of the last 16-channel chunk by the channels r it really holds (Conv3Args::tail): 1: r <= 4, 2: r <= 8, 3: r <= 12,
 // 0: a full chunk -- it is laid out (and run) with fewer, denser k-steps
-// (the half-octet kinds only on tiles of <= 64 channels: conv_igemm3_impl.h, nq_conv3_tail_kind)
 inline int tail_kind_of(int Cin, int mi) {
   const int r = Cin - CC * ((Cin + CC - 1) / CC - 1);
-  if (mi >= 5) return r <= 8 ? 2 : 0;
   return r <= 4 ? 1 : (r <= 8 ? 2 : (r <= 12 ? 3 : 0));
 }
 inline int64_t total_steps3(int Cin, int k, int mi) {

@@ -62,13 +62,17 @@ struct Conv3Args {
 // Timing experiments only (never in the product build): -DNQ_IG3_ABL=n compiles the kernel WITHOUT one of its parts
 // (results are wrong): 1 patch global loads, 2 patch conversion + LDS stores, 3 the MFMAs, 4 the epilogue's global
 // traffic, 5 weight LDS stores, 6 the B-fragment LDS reads, 7 patch loads confined to a 256 KiB window (L2 hits),
-// 8 no patch re-staging after the first chunk, 9 no weight staging after the prologue, 10 both (operands stay random)
+// 8 no patch re-staging after the first chunk, 9 no weight staging after the prologue, 10 both (operands stay random),
+// 11 (LDS-DMA build) no barrier after even k-steps
 // (tools/ablate_igemm3.sh).
 #ifndef NQ_IG3_ABL
 #define NQ_IG3_ABL 0
 #endif
 #ifndef NQ_IG3_R4MIN
 #define NQ_IG3_R4MIN 5   // smallest MI that keeps its weights in a ring of four LDS buffers (one barrier per two k-steps)
+#endif
+#ifndef NQ_IG3_WDMA
+#define NQ_IG3_WDMA 1   // weights by LDS-DMA (buffer_load_dwordx4 ... lds) into a ring of four buffers, three k-steps ahead
 #endif
 #ifndef NQ_IG3_OCC3_DEFAULT
 #define NQ_IG3_OCC3_DEFAULT 40
@@ -96,7 +100,6 @@ constexpr int nst_of_kind(int kind) { return kind == 1 ? NST4 : (kind == 2 ? NST
 // nq_weight_layout3 (conv3.hip), which must lay the operand out the same way
 static inline int nq_conv3_tail_kind(int Cin, int mi) {
   const int r = Cin - 16 * ((Cin + 15) / 16 - 1);
-  if (mi >= 5) return r <= 8 ? 2 : 0;
   return r <= 4 ? 1 : (r <= 8 ? 2 : (r <= 12 ? 3 : 0));
 }
 constexpr int CC = 16;                     // channels per chunk
@@ -139,9 +142,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   u32x4* const patch0 = smem;                  // 1 buffer of PATCH_U4 (re-filled between two barriers per chunk)
   // R4: ring of 4 weight buffers with one barrier per TWO k-steps (measured in one process, per-step barrier -> ring: the
   // 80-channel tile -10 %, the 48/64-channel tiles +2..3 % -- so only MI = 5 takes it); else 2 buffers, barrier per step
-  constexpr bool R4 = (MI >= NQ_IG3_R4MIN);
-  constexpr int WMASK = R4 ? 3 : 1;
-  u32x4* const wl0 = smem + PATCH_U4;          // weight buffers of W_U4: k-step g lives in buffer g & WMASK
+  constexpr bool WDMA = NQ_IG3_WDMA != 0;
+  constexpr bool R4 = !WDMA && (MI >= NQ_IG3_R4MIN);
+  constexpr int WMASK = (R4 || WDMA) ? 3 : 1;
+  // WDMA: the weight operand is already the LDS image ([k-step][plane][kq][MT] 16-byte units, bf16 hi / lo split done by
+  // nq_weight_layout3), so a k-step's W_U4 units go global -> LDS directly: WPT `buffer_load_dwordx4 ... lds` per wave
+  // (1 KiB each: wave-uniform LDS base + lane * 16), no registers, no ds_write, and a prefetch distance of THREE k-steps
+  // into a ring of four buffers at no register cost.  Buffers are WS = WPT * 256 units apart: the lanes past W_U4 in the last
+  // round write into the pad (their source is unit 0: valid memory), so every wave issues exactly WPT pieces per k-step and
+  // the counted waits below are the same for all waves.
+  constexpr int WS = WDMA ? WPT * 256 : W_U4;  // buffer stride in 16-byte units
+  u32x4* const wl0 = smem + PATCH_U4;          // weight buffers: k-step g lives in buffer g & WMASK
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
@@ -241,6 +252,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     if (NQ_IG3_ABL != 5 && (i + 1 < WPT || f_ < W_U4)) (DST)[f_] = SET[i];                            \
   }
 
+  // (the address-space cast of the builtin's LDS operand only exists in the device pass; the host pass of hipcc parses this
+  // body too)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NQ3_DMA_PIECE(DST, VOFF, SOFF) \
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(DST), 16, VOFF, SOFF, 0, 0);
+#else
+#define NQ3_DMA_PIECE(DST, VOFF, SOFF) (void)(DST);
+#endif
+  // WDMA: k-step G -> LDS buffer G & 3 (past the end of the split: the last step again, into a buffer nobody reads)
+#define NQ3_DMA_W(G)                                                                                  \
+  {                                                                                                   \
+    const unsigned so_ = (unsigned)(c_lo * NST + min((int)(G), Gm1)) * w_step_bytes;                  \
+    u32x4* const d_ = wl0 + ((G) & 3) * WS + wave_u * 64;                                             \
+    _Pragma("unroll") for (int i = 0; i < WPT; ++i) NQ3_DMA_PIECE(d_ + i * 256, wvo[i], so_)         \
+  }
+  // counted wait for this wave's LDS-DMA pieces: at most N VMEM operations still in flight
+#define NQ3_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  // workgroup barrier that does NOT drain the VM counter (__syncthreads() waits vmcnt(0) while an LDS-DMA is in flight):
+  // this wave's LDS reads / writes retired, then the bare barrier
+#define NQ3_BARRIER_LDS()                                    \
+  {                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       \
+    __builtin_amdgcn_s_barrier();                            \
+    asm volatile("" ::: "memory");                           \
+  }
+
   f32x4 acc[MI][4];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -272,15 +309,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const int pl_ = f_ / (4 * MT), rem_ = f_ - pl_ * (4 * MT);
     wvo[i] = (unsigned)(cot * 4 * MT + (ok_ ? pl_ * (int)w_plane_stride + rem_ : 0)) * 16u;
   }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  if constexpr (WDMA) {   // steps 0..2 on their way before the patch loads (whose first use below waits for everything)
+    NQ3_DMA_W(0)
+    NQ3_DMA_W(1)
+    NQ3_DMA_W(2)
+  }
   NQ3_LOAD_PATCH(0)
-  NQ3_LOAD_W(wvA, 0)
-  NQ3_LOAD_W(wvB, 1)
+  if constexpr (!WDMA) {
+    NQ3_LOAD_W(wvA, 0)
+    NQ3_LOAD_W(wvB, 1)
+  }
   if (it_neg) {   // first row of the tensor, left halo: the quad was loaded from offset 0 (see it_base)
     const f32x4 v_ = pv[0];
     if constexpr (PAD == 2) pv[0] = f32x4{0.f, 0.f, v_[0], v_[1]};
     else if constexpr (PAD == 1) pv[0] = f32x4{0.f, v_[0], v_[1], v_[2]};
   }
   NQ3_STORE_PATCH(patch0)
+  if constexpr (WDMA) {
+    NQ3_WAIT_VM(0)          // the three k-steps have landed (the patch conversion above waited for its own loads already)
+    NQ3_BARRIER_LDS()
+  } else {
   NQ3_STORE_W(wvA, wl0)
   if constexpr (R4) {
     if (G > 1) {
@@ -290,6 +339,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     NQ3_LOAD_W(wvB, 3)
   }
   __syncthreads();
+  }
 
   // Weight pipeline, R4: k-step g reads LDS buffer g & 3.  During step g (in the middle of its MFMA block) register set g & 1,
   // which holds the weights of step g+2 (loaded two steps ago), is published into buffer (g+2) & 3 and re-armed with the
@@ -309,7 +359,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       constexpr int st = decltype(st_c)::value;
       constexpr int gp = (PAR + st) & 1;  // parity of the global step
       const int g = g0 + st;
-      if constexpr (!R4 && NQ_IG3_ABL != 9 && NQ_IG3_ABL != 10) {   // ablations 9 / 10: the weights of the first steps for all
+      // WDMA: k-step g+3 into buffer (g+3) & 3 = (g-1) & 3, whose last readers passed the barrier that ended step g-1.  In
+      // the last step of a full chunk the pieces are issued AFTER the patch conversion instead (below): the conversion is the
+      // first use of ordinary loads, where hipcc drains the VM counter -- with the newest pieces not yet issued that costs
+      // nothing that was not needed anyway.
+      constexpr bool LATE_DMA = WDMA && !TAIL && st == NST - 1;
+      if constexpr (WDMA && !LATE_DMA) NQ3_DMA_W(g + 3)
+      if constexpr (!WDMA && !R4 && NQ_IG3_ABL != 9 && NQ_IG3_ABL != 10) {   // ablations 9 / 10: the weights of the first steps for all
         if constexpr (gp == 0) {
           NQ3_LOAD_W(wvA, g + 2)
         } else {
@@ -378,7 +434,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         bl[nb] = __builtin_bit_cast(bf16x8, pbt[2 * PP + o]);
       }
       }
-      const u32x4* __restrict__ wb = wl0 + (g & WMASK) * W_U4 + a_lane;
+      const u32x4* __restrict__ wb = wl0 + (g & WMASK) * WS + a_lane;
       bf16x8 ah0 = __builtin_bit_cast(bf16x8, wb[0]), al0 = __builtin_bit_cast(bf16x8, wb[4 * MT]);
       steps3<0, MI>([&](auto mi_c) {
         constexpr int mi = decltype(mi_c)::value;
@@ -407,7 +463,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         if constexpr (mi == (MI - 1) / 2) {
           // publish the next weights in the MIDDLE of the MFMA block (the LDS write latency is covered by the remaining
           // MFMAs instead of sitting in front of the barrier)
-          if constexpr (NQ_IG3_ABL == 9 || NQ_IG3_ABL == 10) {
+          if constexpr (NQ_IG3_ABL == 9 || NQ_IG3_ABL == 10 || WDMA) {
           } else if constexpr (R4) {   // step g+2 from set g & 1, which is then re-armed with the loads of step g+4
             if (g + 2 < G) {
               u32x4* wdst = wl0 + ((g + 2) & 3) * W_U4;
@@ -432,9 +488,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
               }
             }
           }
-          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (!WDMA) __builtin_amdgcn_sched_barrier(0);
         }
       });
+      if constexpr (WDMA) {
+        // End of step g: this wave's pieces of step g+1 must have landed before the barrier; every wave's, after it -- the
+        // fragments of step g+1 are read one barrier AFTER the wait that retires them.  In flight behind them: steps g+2 and
+        // g+3 (2 x WPT pieces; patch loads issued in between only make the count conservative).
+        if constexpr (LATE_DMA) {
+          NQ3_WAIT_VM(WPT)        // only step g+2 behind step g+1 (the chunk's patch loads are older than both)
+          NQ3_BARRIER_LDS()       // every wave is done with the current patch
+          if (ch + 1 < nchunk) {
+            NQ3_STORE_PATCH(patch0)
+          }
+          NQ3_DMA_W(g + 3)
+          NQ3_BARRIER_LDS()
+        } else if constexpr (NQ_IG3_ABL == 11 && (st & 1) == 0) {   // timing only: no barrier after even steps (races)
+          NQ3_WAIT_VM(2 * WPT)
+        } else {
+          NQ3_WAIT_VM(2 * WPT)
+          NQ3_BARRIER_LDS()
+        }
+      } else {
       if constexpr (!TAIL && st == NST - 1) {
         if (NQ_IG3_ABL != 8 && NQ_IG3_ABL != 10 && ch + 1 < nchunk) {   // ablations 8 / 10: every chunk re-uses the first patch
           __syncthreads();  // every wave is done with the current patch
@@ -442,6 +517,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         }
       }
       if constexpr (!R4 || (st & 1) != 0 || st == NSTC - 1) __syncthreads();
+      }
     });
   };
   using C0 = std::integral_constant<int, 0>;
@@ -455,9 +531,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     using K1 = std::integral_constant<int, 1>;
     using K2 = std::integral_constant<int, 2>;
     using K3 = std::integral_constant<int, 3>;
-    // the half-octet kinds exist for MI <= 4 only (nq_conv3_tail_kind): on the 80-channel tile, already at 256 VGPRs, their
-    // two per-lane-group offsets spilled into the K loop (dec5 forward 387 -> 476 us)
-    if constexpr (MI <= 4) {
+    // (the half-octet kinds on the 80-channel tile too since the weights travel by LDS-DMA: with the two weight register sets
+    // gone the kernel holds 252 VGPRs without scratch; with them these kinds spilled into their k-steps, 387 -> 476 us)
+    {
       if (tail == 1) {
         if (odd) run_chunk(C1{}, K1{}, nfull);
         else run_chunk(C0{}, K1{}, nfull);
@@ -471,6 +547,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       else run_chunk(C0{}, K2{}, nfull);
     }
   }
+  if constexpr (WDMA) {   // the pieces issued past the end of the split must not land in LDS the epilogue re-uses
+    NQ3_WAIT_VM(0)
+    NQ3_BARRIER_LDS()
+  }
+#undef NQ3_DMA_W
+#undef NQ3_DMA_PIECE
+#undef NQ3_WAIT_VM
+#undef NQ3_BARRIER_LDS
 #undef NQ3_LOAD_PATCH
 #undef NQ3_STORE_PATCH
 #undef NQ3_LOAD_W
@@ -692,6 +776,7 @@ template <int MI>
 int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
   constexpr int MT = 16 * MI;
   size_t lds = (size_t)(PATCH_U4 + (MI >= NQ_IG3_R4MIN ? 4 : 2) * 2 * 4 * MT) * 16;   // patch + weight buffers (ring of 4 for MI = 5)
+  if (NQ_IG3_WDMA) lds = (size_t)(PATCH_U4 + 4 * ((2 * 4 * MT + 255) / 256) * 256) * 16;  // ring of 4, padded to whole 256-unit rounds
   Conv3Args a = a_in;
   a.lds_epi = 0;
   if (a.epi == NQ_EPI_DGRAD_GELU && a.nsplit == 1 && MI <= 4) {   // 4 waves x [MT][64] floats for the wide epilogue

@@ -197,6 +197,8 @@ def mask_agreement(qnn_a, qnn_b):
 
 def run(args, log=print):
     dev = torch.device("cuda", 0)
+    if not hasattr(args, "arch"):   # callers that build their own namespace (tests/test_full_size.py)
+        args.arch = "hnerv"
     n, B = args.frames_n, 2
     if args.frames == "bunny":
         frames_u8 = bunny_frames_640(dev, n)
