@@ -29,6 +29,7 @@ Prints ONE JSON line (rank 0) with
                   (48 iterations, first 4 discarded).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -226,6 +227,11 @@ def main():
             if W < done < steps_total:
                 ops.profile_sample((done - W) % PROF_EVERY == 0)
             if done == W:
+                # the two profiled iterations of the timed region run eagerly (hundreds of Python calls each): a generation-2
+                # garbage collection landing in one of them costs ~10 ms of host time = 0.9 ms/step on the 20-step average
+                # (seen as a 310 it/s outlier among the repeats).  Collect before, not during.
+                gc.collect()
+                gc.disable()
                 sync()
                 if not os.environ.get("NQ_BENCH_NOPROF"):
                     ops.profile_start()
@@ -236,6 +242,7 @@ def main():
                 t["t_enq"] = time.perf_counter()   # host finished enqueueing the timed steps (before the device drains)
                 sync()
                 t["t1"] = time.perf_counter()
+                gc.enable()
                 t["prof"] = ops.profile_stop() if not os.environ.get("NQ_BENCH_NOPROF") else {}
 
         # iters = 20 * len(loader): int(0.05 * iters / len) = 1 phase-1 epoch of W+K+1 iterations, cut after W+K by max_steps

@@ -128,10 +128,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 }
 
 // WPE = waves per SIMD the register allocation aims at: 2 for the long K loops (the MFMA-bound layers: a third wave only
-// queues for the same matrix pipe and its registers are better spent on prefetch depth), 3 for the 16-/32-channel tiles
-// on short K loops (the data gradients of NeRV's last blocks, 96 -> 24 channels: <= 30 k-steps between a prologue and an
-// epilogue of global-memory latency -- bound by latency, not by issue slots: 104 -> 91 us at 320x640, tools/bench_nerv_tail.py).
-// The 48-channel tile does not fit 168 registers (264 B of scratch: 132 -> 202 us) and stays at 2.
+// queues for the same matrix pipe), 3 for the tiles of <= 48 channels on short K loops (NeRV's last blocks: <= 30 k-steps
+// between a prologue and an epilogue of global-memory latency -- bound by latency, not by issue slots; tools/bench_nerv_tail.py).
+// With the weights travelling by LDS-DMA the 48-channel tile holds 167 VGPRs and 48.5 KB of LDS: three workgroups per CU
+// (with two weight register sets it needed 264 B of scratch for that: 132 -> 202 us).
 template <int MI, int WPE = 2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void conv_igemm3_kernel(Conv3Args a) {
   constexpr int MT = 16 * MI;
@@ -142,17 +142,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   u32x4* const patch0 = smem;                  // 1 buffer of PATCH_U4 (re-filled between two barriers per chunk)
   // R4: ring of 4 weight buffers with one barrier per TWO k-steps (measured in one process, per-step barrier -> ring: the
   // 80-channel tile -10 %, the 48/64-channel tiles +2..3 % -- so only MI = 5 takes it); else 2 buffers, barrier per step
-  constexpr bool WDMA = NQ_IG3_WDMA != 0;
+  constexpr bool WDMA = NQ_IG3_WDMA != 0 && MI >= 3;   // (narrow tiles: see below)
   constexpr bool R4 = !WDMA && (MI >= NQ_IG3_R4MIN);
-  constexpr int WMASK = (R4 || WDMA) ? 3 : 1;
+  // WDMA ring: NB buffers, k-step g+D fetched during step g (D = NB - 1): 3 steps of ~1 us cover an L2 round trip.
+  // The 16-/32-channel tiles keep the register staging: their k-steps hold 12-24 MFMAs, and one LDS-DMA piece per step
+  // costs a wave more issue time than a load + ds_write pair (NeRV's 96 -> 24 data gradient at 320x640: 90 us with
+  // registers at three waves per SIMD, 97 us with a ring of four, 103 us with a ring of eight).
+  constexpr int NB = 4, WD = NB - 1;
+  constexpr int WMASK = WDMA ? NB - 1 : (R4 ? 3 : 1);
   // WDMA: the weight operand is already the LDS image ([k-step][plane][kq][MT] 16-byte units, bf16 hi / lo split done by
   // nq_weight_layout3), so a k-step's W_U4 units go global -> LDS directly: WPT `buffer_load_dwordx4 ... lds` per wave
   // (1 KiB each: wave-uniform LDS base + lane * 16), no registers, no ds_write, and a prefetch distance of THREE k-steps
-  // into a ring of four buffers at no register cost.  Buffers are WS = WPT * 256 units apart: the lanes past W_U4 in the last
-  // round write into the pad (their source is unit 0: valid memory), so every wave issues exactly WPT pieces per k-step and
-  // the counted waits below are the same for all waves.
-  constexpr int WS = WDMA ? WPT * 256 : W_U4;  // buffer stride in 16-byte units
+  // into a ring of four buffers at no register cost.  Every wave issues exactly WPT pieces per k-step, so that the counted
+  // waits below are the same for all waves: the pieces past W_U4 in the last round (W_U4 is a multiple of 128 units, a
+  // piece is 64: whole pieces) land in a dump area behind the ring (their source is unit 0: valid memory).
+  constexpr int WS = W_U4;                     // buffer stride in 16-byte units
+  constexpr int WDUMP = WPT * 256 - W_U4;      // units of the dump area (0 for the 32- and 64-channel tiles)
   u32x4* const wl0 = smem + PATCH_U4;          // weight buffers: k-step g lives in buffer g & WMASK
+  u32x4* const wdump = wl0 + NB * W_U4;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
@@ -260,12 +267,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 #else
 #define NQ3_DMA_PIECE(DST, VOFF, SOFF) (void)(DST);
 #endif
-  // WDMA: k-step G -> LDS buffer G & 3 (past the end of the split: the last step again, into a buffer nobody reads)
+  // WDMA: k-step G -> LDS buffer G & (NB - 1) (past the end of the split: the last step again, into a buffer nobody reads)
 #define NQ3_DMA_W(G)                                                                                  \
   {                                                                                                   \
     const unsigned so_ = (unsigned)(c_lo * NST + min((int)(G), Gm1)) * w_step_bytes;                  \
-    u32x4* const d_ = wl0 + ((G) & 3) * WS + wave_u * 64;                                             \
-    _Pragma("unroll") for (int i = 0; i < WPT; ++i) NQ3_DMA_PIECE(d_ + i * 256, wvo[i], so_)         \
+    u32x4* const d_ = wl0 + ((G) & (NB - 1)) * WS + wave_u * 64;                                             \
+    _Pragma("unroll") for (int i = 0; i < WPT; ++i) {                                                 \
+      if (WDUMP == 0 || i + 1 < WPT) NQ3_DMA_PIECE(d_ + i * 256, wvo[i], so_)                         \
+      else NQ3_DMA_PIECE((i * 256 + wave_u * 64 < W_U4) ? d_ + i * 256 : wdump + (i * 256 + wave_u * 64 - W_U4), wvo[i], so_) \
+    }                                                                                                 \
   }
   // counted wait for this wave's LDS-DMA pieces: at most N VMEM operations still in flight
 #define NQ3_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -310,10 +320,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     wvo[i] = (unsigned)(cot * 4 * MT + (ok_ ? pl_ * (int)w_plane_stride + rem_ : 0)) * 16u;
   }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  if constexpr (WDMA) {   // steps 0..2 on their way before the patch loads (whose first use below waits for everything)
-    NQ3_DMA_W(0)
-    NQ3_DMA_W(1)
-    NQ3_DMA_W(2)
+  if constexpr (WDMA) {   // steps 0..D-1 on their way before the patch loads (whose first use below waits for everything)
+    steps3<0, WD>([&](auto q_c) { NQ3_DMA_W(decltype(q_c)::value) });
   }
   NQ3_LOAD_PATCH(0)
   if constexpr (!WDMA) {
@@ -359,12 +367,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       constexpr int st = decltype(st_c)::value;
       constexpr int gp = (PAR + st) & 1;  // parity of the global step
       const int g = g0 + st;
-      // WDMA: k-step g+3 into buffer (g+3) & 3 = (g-1) & 3, whose last readers passed the barrier that ended step g-1.  In
+      // WDMA: k-step g+D into buffer (g+D) & (NB-1) = (g-1) & (NB-1), whose last readers passed the barrier that ended step g-1.  In
       // the last step of a full chunk the pieces are issued AFTER the patch conversion instead (below): the conversion is the
       // first use of ordinary loads, where hipcc drains the VM counter -- with the newest pieces not yet issued that costs
       // nothing that was not needed anyway.
       constexpr bool LATE_DMA = WDMA && !TAIL && st == NST - 1;
-      if constexpr (WDMA && !LATE_DMA) NQ3_DMA_W(g + 3)
+      if constexpr (WDMA && !LATE_DMA) NQ3_DMA_W(g + WD)
       if constexpr (!WDMA && !R4 && NQ_IG3_ABL != 9 && NQ_IG3_ABL != 10) {   // ablations 9 / 10: the weights of the first steps for all
         if constexpr (gp == 0) {
           NQ3_LOAD_W(wvA, g + 2)
@@ -493,20 +501,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       });
       if constexpr (WDMA) {
         // End of step g: this wave's pieces of step g+1 must have landed before the barrier; every wave's, after it -- the
-        // fragments of step g+1 are read one barrier AFTER the wait that retires them.  In flight behind them: steps g+2 and
-        // g+3 (2 x WPT pieces; patch loads issued in between only make the count conservative).
+        // fragments of step g+1 are read one barrier AFTER the wait that retires them.  In flight behind them: steps g+2 ..
+        // g+D ((D-1) x WPT pieces; patch loads issued in between only make the count conservative).
         if constexpr (LATE_DMA) {
-          NQ3_WAIT_VM(WPT)        // only step g+2 behind step g+1 (the chunk's patch loads are older than both)
+          NQ3_WAIT_VM((WD - 2) * WPT)   // only steps g+2 .. g+D-1 behind step g+1 (the chunk's patch loads are older than all)
           NQ3_BARRIER_LDS()       // every wave is done with the current patch
           if (ch + 1 < nchunk) {
             NQ3_STORE_PATCH(patch0)
           }
-          NQ3_DMA_W(g + 3)
+          NQ3_DMA_W(g + WD)
           NQ3_BARRIER_LDS()
         } else if constexpr (NQ_IG3_ABL == 11 && (st & 1) == 0) {   // timing only: no barrier after even steps (races)
-          NQ3_WAIT_VM(2 * WPT)
+          NQ3_WAIT_VM((WD - 1) * WPT)
         } else {
-          NQ3_WAIT_VM(2 * WPT)
+          NQ3_WAIT_VM((WD - 1) * WPT)
           NQ3_BARRIER_LDS()
         }
       } else {
@@ -776,7 +784,7 @@ template <int MI>
 int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
   constexpr int MT = 16 * MI;
   size_t lds = (size_t)(PATCH_U4 + (MI >= NQ_IG3_R4MIN ? 4 : 2) * 2 * 4 * MT) * 16;   // patch + weight buffers (ring of 4 for MI = 5)
-  if (NQ_IG3_WDMA) lds = (size_t)(PATCH_U4 + 4 * ((2 * 4 * MT + 255) / 256) * 256) * 16;  // ring of 4, padded to whole 256-unit rounds
+  if (NQ_IG3_WDMA && MI >= 3) lds = (size_t)(PATCH_U4 + 4 * (2 * 4 * MT) + ((2 * 4 * MT + 255) / 256 * 256 - 2 * 4 * MT)) * 16;  // ring of 4 + dump area
   Conv3Args a = a_in;
   a.lds_epi = 0;
   if (a.epi == NQ_EPI_DGRAD_GELU && a.nsplit == 1 && MI <= 4) {   // 4 waves x [MT][64] floats for the wide epilogue
@@ -784,7 +792,7 @@ int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
     if (lds < (size_t)MT * 1024) lds = (size_t)MT * 1024;
   }
   a.tiles = tiles;
-  if constexpr (MI <= 2) {
+  if constexpr (MI <= 3) {
     // short K loop -> the three-waves-per-SIMD build (NQ_IG3_OCC3_STEPS: largest k-step count that takes it; 0 = never)
     static const int occ3_steps = [] { const char* e = getenv("NQ_IG3_OCC3_STEPS"); return e ? atoi(e) : NQ_IG3_OCC3_DEFAULT; }();
     const int ksteps = (a.nsplit > 1 ? a.per_split : a.nchunk - 1) * NST + (a.nsplit > 1 ? 0 : nst_of_kind(a.tail));
