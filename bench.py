@@ -59,6 +59,10 @@ PEAK_HBM_BPS = 8.0e12
 FLAGS = dict(weight=0.01, b_range=(20, 2), lr=0.003)
 PROF_EVERY = 10  # HIP events around the conv launches of every 10th timed step: those steps are launched eagerly (~1.2 ms of
                  # host work each), all others are hipGraph replays
+PROF_PHASE = 5   # ... the 6th, 16th, ... timed step: by then the host is several replays (>= 10 ms of GPU work) ahead of the
+                 # device, so the eager enqueue of a profiled step is hidden even on a box with a slow host (profiling the
+                 # FIRST timed step, right behind the synchronisation that opens the region, exposed it: one box with 9 ms
+                 # per eager step read 340 instead of 450 it/s)
 
 
 def build_model(seed=903, workload="hnerv"):
@@ -220,12 +224,13 @@ def main():
         # int(0.05*iters/len) = 0 phase-1 epochs and exactly one phase-2 epoch, for any K
         loader = CacheLoader(cache, list(range(n_frames)), gB, seed=903, rank=rank, world=world, epoch_batches=steps_total + 1)
         t = {}
+        phase = PROF_PHASE if K > PROF_PHASE else 0
 
         def hook(done):
             if os.environ.get("NQ_BENCH_STEPLOG"):   # debugging: host time at every iteration boundary -> stderr
                 t.setdefault("log", []).append((done, time.perf_counter()))
             if W < done < steps_total:
-                ops.profile_sample((done - W) % PROF_EVERY == 0)
+                ops.profile_sample((done - W) % PROF_EVERY == phase)
             if done == W:
                 # the two profiled iterations of the timed region run eagerly (hundreds of Python calls each): a generation-2
                 # garbage collection landing in one of them costs ~10 ms of host time = 0.9 ms/step on the 20-step average
@@ -235,6 +240,7 @@ def main():
                 sync()
                 if not os.environ.get("NQ_BENCH_NOPROF"):
                     ops.profile_start()
+                    ops.profile_sample(phase == 0)
                 t["t0"] = time.perf_counter()
             elif done == steps_total and "t1" not in t:
                 # (first arrival only: after a phase-1 run model_reconstruction goes on to set phase 2 up and its first
@@ -262,7 +268,7 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         if use_dist:
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        prof_steps = len([d for d in range(W, steps_total) if (d - W) % PROF_EVERY == 0])
+        prof_steps = len([d for d in range(W, steps_total) if (d - W) % PROF_EVERY == phase])
         del qnn, model
         torch.cuda.empty_cache()
         return dict(elapsed=float(tmax.item()), t_enq=t["t_enq"] - t["t0"], prof=t["prof"], avg_bits=avg_bits,

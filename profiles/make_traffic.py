@@ -13,22 +13,26 @@ import json
 import sys
 
 # bench key -> (kernel name in the PMC summary, grid size) for HNeRV Bunny_1280x640_3M, B = 2
+# (conv_igemm3_kernel<MI, WPE>: channel blocks per tile, waves per SIMD the build aims at)
 MAP = {
     "conv_wgrad3_k5_44_148": ("conv_wgrad3p_kernel<5, 6, 1, 4>", None),
-    "conv_igemm3_k5_44_148": ("conv_igemm3_kernel<5>", 819200),
-    "conv_igemm3_k3_24_96": ("conv_igemm3_kernel<3>", 819200),
-    "conv_igemm3_k5_148_44": ("conv_igemm3_kernel<3>", 409600),
+    "conv_igemm3_k5_44_148": ("conv_igemm3_kernel<5, 2>", 819200),
+    "conv_igemm3_k3_24_96": ("conv_igemm3_kernel<3, 3>", 819200),
+    "conv_igemm3_k5_148_44": ("conv_igemm3_kernel<3, 2>", 409600),
     "conv_wgrad3_k5_53_176": ("conv_wgrad3p_kernel<4, 7, 1, 4>", None),
-    "conv_igemm3_k5_53_176": ("conv_igemm3_kernel<4>", 307200),
-    "conv_igemm3_k5_176_53": ("conv_igemm3_kernel<4>", 102400),
+    "conv_igemm3_k5_53_176": ("conv_igemm3_kernel<4, 2>", 307200),
+    "conv_igemm3_k5_176_53": ("conv_igemm3_kernel<4, 2>", 102400),
 }
 
 
-def main(src):
-    rows = json.load(open(src))
+def main(*srcs):
+    rows = []
+    for src_ in srcs:   # (the HNeRV set, optionally the NeRV set: its 24 -> 96 forward is the `nerv` object's dominant kernel)
+        rows += [dict(r, _src=src_) for r in json.load(open(src_))]
     out = {}
     for key, (name, grid) in MAP.items():
         for r in rows:
+            src = r["_src"]
             if r["kernel"] == name and (grid is None or r["grid"] == grid):
                 if r.get("clock_suspect") or ((r.get("clock_GHz") or 0) > 2.45 and r["dur_us"] >= 300):
                     raise SystemExit(f"{name}: clock {r.get('clock_GHz')} GHz on a {r['dur_us']} us dispatch -- broken PMC pass, "
@@ -43,4 +47,4 @@ def main(src):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(*sys.argv[1:])
