@@ -1267,3 +1267,15 @@ def test_full_size_parity_hnerv_3m(ops):
     assert res["psnr_diff_q_opt_dB"] < 0.02, res
     assert res["loss_rel_diff_max"] < 1e-4, res
     assert abs(res["gpu"]["q_noopt"] - res["cpu"]["q_noopt"]) < 0.02 and abs(res["gpu"]["fp"] - res["cpu"]["fp"]) < 0.02
+
+
+@pytest.mark.gpu
+def test_igemm3_lds_dma_launches_repeat_bit_for_bit():
+    """conv_igemm3 with its weights arriving by LDS-DMA: every repetition of a launch reproduces the first
+    bit for bit, with and without a second stream loading HBM / the L2s (tools/race_screen.py; an early fragment read would
+    show as a few differing words in some repetition).  Long form: `python tools/race_screen.py --reps 60`."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import race_screen
+    assert race_screen.screen(8, only={"hnerv dec4", "hnerv dec2", "nerv blk5", "ragged"}) == 0
