@@ -132,6 +132,33 @@ class _Layer:
         self.W = self.b = None
 
 
+_AVG_OK = {}    # backend name -> the backend reduces with ReduceOp.AVG (RCCL does; gloo refuses it)
+
+
+def _mean_all_reduce(t):
+    """Asynchronous in-place mean of `t` over the ranks; -> a function that completes it (the compute stream waits for the
+    collective -- no host synchronisation with RCCL).  ReduceOp.AVG where the backend has it (RCCL: the division happens
+    inside the collective, one pass over the arena), else SUM and a scale after the wait (gloo: CPU tests and GPU
+    rehearsals of the multi-process path)."""
+    import torch.distributed as dist
+    be = dist.get_backend()
+    if _AVG_OK.get(be, True):
+        try:
+            w = dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
+            _AVG_OK[be] = True
+            return w.wait
+        except (RuntimeError, ValueError, NotImplementedError):
+            _AVG_OK[be] = False
+    w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+    scale = 1.0 / dist.get_world_size()
+
+    def fin():
+        w.wait()
+        if scale != 1.0:
+            t.mul_(scale)
+    return fin
+
+
 def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: str = 'hnerv', batch_size: int = 8,
                          iters: int = 20000, weight: float = 0.01, opt_mode: str = 'mse', hadamard: bool = True,
                          b_range: tuple = (20, 2), warmup: float = 0.0, p: float = 2.0, lr: float = 0.0015,
@@ -171,10 +198,10 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
         pending = []
 
         def reduce_part(part, last=True):
-            pending.append(dist.all_reduce(part, op=dist.ReduceOp.AVG, async_op=True))
+            pending.append(_mean_all_reduce(part))
             if last:   # the compute stream waits for both collectives (no host sync)
-                for w in pending:
-                    w.wait()
+                for fin in pending:
+                    fin()
                 pending.clear()
 
         hook_scope = ops.grad_arena_hook(reduce_part, two_phase=os.environ.get("NQ_DP_OVERLAP", "1") != "0")
@@ -243,9 +270,9 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
         works = []
         for g, part in zip(graphs[:-1], parts):
             g.replay()
-            works.append(dist.all_reduce(part, op=dist.ReduceOp.AVG, async_op=True))
-        for w in works:   # the compute stream waits for them (no host sync)
-            w.wait()
+            works.append(_mean_all_reduce(part))
+        for fin in works:   # the compute stream waits for them (no host sync)
+            fin()
         graphs[-1].replay()
 
     def run(epochs, params, opt_lr, max_count, ada):

@@ -393,3 +393,48 @@ def test_captured_dp_iterations_equal_eager(golden, rehearsal_env, monkeypatch):
         for key in ("delta", "alpha"):
             assert all(torch.equal(x, y) for x, y in zip(runs[r][key], cap[r][key]))
     assert all(torch.equal(x, y) for x, y in zip(cap[0]["alpha"] + cap[0]["delta"], cap[1]["alpha"] + cap[1]["delta"]))
+
+
+def test_two_processes_gloo_on_gpu(golden, tmp_path, monkeypatch):
+    """A REAL world of two: two processes on this GPU, different frames on each, a genuine collective between them (gloo:
+    RCCL refuses two ranks on one device) through the product path -- sharded CacheLoader, ops.grad_arena_hook, the
+    asynchronous in-place mean all-reduce of the two arena parts (SUM + scale where the backend has no AVG).  Both replicas
+    must end bit-identical, and equal the single-process run of the global batch to summation-order tolerance."""
+    import subprocess
+    import sys
+    port = _free_port()
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_dp_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NQ_DP_REHEARSAL"):
+        env.pop(k, None)
+    outs = [str(tmp_path / f"rank{r}.npz") for r in (0, 1)]
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), outs[r]], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in (0, 1)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=300)[0].decode(errors="replace"))
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-2000:] for l in logs)
+    r0, r1 = np.load(outs[0]), np.load(outs[1])
+    keys = [k for k in r0.files if k != "log"]
+    assert keys and all(np.array_equal(r0[k], r1[k]) for k in keys), "replicas diverged"
+    # each rank logs ITS shard's reconstruction loss: they differ (different frames), their mean is the global-batch loss
+    assert r0["log"].shape == r1["log"].shape == (5, 4)
+    assert np.abs(r0["log"][:, 0] - r1["log"][:, 0]).max() > 0
+
+    single = _engine_run(golden, monkeypatch, 0, 1, None)          # the whole batch of 4 in this process, no exchange
+    rec_mean = 0.5 * ((r0["log"][:, 0] - r0["log"][:, 1]) + (r1["log"][:, 0] - r1["log"][:, 1]))
+    rec_single = single["log"][:, 0] - single["log"][:, 1]
+    assert np.abs(rec_mean - rec_single).max() <= 2e-4 * np.abs(rec_single).max(), (rec_mean, rec_single)
+    qi = 0
+    for i in range(len(single["delta"]) // 2):
+        for tag in ("w", "b"):
+            d, a = single["delta"][qi].cpu().numpy(), single["alpha"][qi].cpu().numpy()
+            qi += 1
+            assert np.abs(r0[f"delta_{tag}{i}"] - d).max() <= 1e-3 * np.abs(d).max()
+            if a.size >= 1000:   # alpha moves by lr per step: a few elements flip sign of a near-zero gradient
+                assert (np.abs(r0[f"alpha_{tag}{i}"] - a) > 0.05).mean() < 0.01
