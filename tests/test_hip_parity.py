@@ -260,7 +260,11 @@ def test_conv_forward_backward(ops, case):
                                   (2, 30, 120, 240, 40, 5, "dgrad", 3),
                                   # last channel chunk in every tail mode (<= 4 / 5..8 / 9..12 channels), alone and behind full chunks
                                   (2, 12, 32, 64, 48, 5, "plain", 1), (2, 36, 32, 64, 48, 3, "psgelu", 2),
-                                  (2, 7, 32, 64, 32, 5, "plain", 1), (2, 28, 32, 64, 80, 3, "plain", 1)])
+                                  (2, 7, 32, 64, 32, 5, "plain", 1), (2, 28, 32, 64, 80, 3, "plain", 1),
+                                  # K loops SHORTER than the LDS-DMA ring's prefetch distance (2 / 4 / 2 k-steps on the 48-, 80-
+                                  # and 64-channel tiles), and a ring that wraps many times behind a split-K (deep, narrow input)
+                                  (2, 3, 32, 64, 48, 3, "psgelu", 2), (2, 4, 32, 64, 80, 5, "plain", 1),
+                                  (2, 2, 40, 72, 64, 3, "tanh", 1), (1, 333, 8, 32, 48, 3, "plain", 1)])
 def test_conv_bf16x3(ops, case):
     """bf16x3 kernel (split operands on the BF16 matrix pipe) vs float64: error stays at the fp32 level (a few 1e-6
     relative to the output scale), forward epilogues and the data-gradient operand (transposed=True) included.  Grids
