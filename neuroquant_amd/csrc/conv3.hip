@@ -323,45 +323,65 @@ struct WGRMulti {
   int blk0[WGR_MAXSEG + 1];
   int nseg;
 };
+// (round 3: a thread owns FOUR consecutive n of one channel -- one 16-byte load per slab instead of four 4-byte ones; the
+// launch read 115 MB of slabs at 2.8 TB/s with scalar loads.  Per output the slabs are still added in the order
+// j = g, g + SG, ... and the SG partial sums in the order 0 .. SG-1: bit-identical to the scalar form.)
 __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WGRMulti t) {
-  __shared__ float part[256];
+  __shared__ float4 part[256];
   int k = 0;
   while (k + 1 < t.nseg && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
   const nq_wgr_seg& q = t.s[k];
   const int SG = q.sg, OG = 256 / SG;
   const int o = threadIdx.x % OG, g = threadIdx.x / OG;
   const int N = q.N, Cout = q.Cout, nsplit = q.nsplit;
-  const int64_t i = (int64_t)((int)blockIdx.x - t.blk0[k]) * OG + o;
-  const int64_t total = (int64_t)Cout * N;
-  float s = 0.f;
+  const int NQ = (N + 3) >> 2;                                   // quads per channel (n_pad is a multiple of 16)
+  const int64_t i = (int64_t)((int)blockIdx.x - t.blk0[k]) * OG + o;   // quad index, then the bias entries
+  const int64_t total = (int64_t)Cout * NQ;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  int co = 0, n = 0;
   if (i < total) {
-    const int co = (int)(i / N), n = (int)(i - (int64_t)co * N);
+    co = (int)(i / NQ);
+    n = 4 * (int)(i - (int64_t)co * NQ);
     const float* p = q.slab + (int64_t)co * q.n_pad + n;
     const int64_t stride = (int64_t)q.co_pad * q.n_pad;
 #pragma unroll 4
-    for (int j = g; j < nsplit; j += SG) s += p[j * stride];
+    for (int j = g; j < nsplit; j += SG) {
+      const float4 v = *reinterpret_cast<const float4*>(p + j * stride);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   } else if (q.db && i < total + Cout) {
-    const int co = (int)(i - total);
+    const int cb = (int)(i - total);
 #pragma unroll 4
-    for (int j = g; j < nsplit; j += SG) s += q.slab_db[(int64_t)j * q.co_pad + co];
+    for (int j = g; j < nsplit; j += SG) s.x += q.slab_db[(int64_t)j * q.co_pad + cb];
   }
   if (SG > 1) {   // block-uniform
     part[g * OG + o] = s;
     __syncthreads();
     if (g != 0) return;
     s = part[o];
-    for (int j = 1; j < SG; ++j) s += part[j * OG + o];
+    for (int j = 1; j < SG; ++j) {
+      const float4 v = part[j * OG + o];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
   if (i < total) {
+    const float sv[4] = {s.x, s.y, s.z, s.w};
     if (q.swap_kk > 0) {
-      const int co = (int)(i / N), n = (int)(i - (int64_t)co * N);
-      const int ci = n / q.swap_kk, tap = n - ci * q.swap_kk;
-      q.dw[((int64_t)ci * Cout + co) * q.swap_kk + (q.swap_kk - 1 - tap)] = s;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (n + e >= N) break;
+        const int ci = (n + e) / q.swap_kk, tap = (n + e) - ci * q.swap_kk;
+        q.dw[((int64_t)ci * Cout + co) * q.swap_kk + (q.swap_kk - 1 - tap)] = sv[e];
+      }
+    } else if ((N & 3) == 0) {
+      *reinterpret_cast<float4*>(q.dw + (int64_t)co * N + n) = s;
     } else {
-      q.dw[i] = s;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n + e < N) q.dw[(int64_t)co * N + n + e] = sv[e];
     }
   } else if (q.db && i < total + Cout) {
-    q.db[(int)(i - total)] = s;
+    q.db[(int)(i - total)] = s.x;
   }
 }
 
@@ -515,7 +535,7 @@ int nq_wgrad_reduce_multi(const nq_wgr_seg* segs, int nseg, nq_stream_t stream) 
     t.s[t.nseg] = h;
     t.blk0[t.nseg] = blocks;
     const int og = 256 / h.sg;
-    blocks += (int)(((int64_t)h.Cout * h.N + h.Cout + og - 1) / og);
+    blocks += (int)(((int64_t)h.Cout * ((h.N + 3) / 4) + h.Cout + og - 1) / og);   // quads of n, then the bias entries
     ++t.nseg;
   }
   flush();
