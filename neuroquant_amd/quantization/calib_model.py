@@ -132,14 +132,13 @@ class _Layer:
         self.W = self.b = None
 
 
-_AVG_OK = {}    # backend name -> the backend reduces with ReduceOp.AVG (RCCL does; gloo refuses it)
+_AVG_OK = {}    # backend name -> the backend reduces with ReduceOp.AVG (RCCL does, this image's gloo too; older gloo refuses it)
 
 
 def _mean_all_reduce(t):
     """Asynchronous in-place mean of `t` over the ranks; -> a function that completes it (the compute stream waits for the
     collective -- no host synchronisation with RCCL).  ReduceOp.AVG where the backend has it (RCCL: the division happens
-    inside the collective, one pass over the arena), else SUM and a scale after the wait (gloo: CPU tests and GPU
-    rehearsals of the multi-process path)."""
+    inside the collective, one pass over the arena), else SUM and a scale after the wait (a backend that refuses AVG)."""
     import torch.distributed as dist
     be = dist.get_backend()
     if _AVG_OK.get(be, True):

@@ -72,6 +72,15 @@ def _worker(rank, world, port, out):
         gl = [gw_local.clone()]
         allreduce_mean_(gl)
         assert torch.allclose(gl[0], gw_global, rtol=1e-6)
+        # the engine's arena exchange (calib_model._mean_all_reduce): asynchronous in-place mean of two views of one arena
+        # (ReduceOp.AVG where the backend takes it, else SUM and a scale after the wait: decided once per backend)
+        from neuroquant_amd.quantization import calib_model as cm
+        arena = torch.arange(10, dtype=torch.float32) * (rank + 1)
+        fins = [cm._mean_all_reduce(arena[:6]), cm._mean_all_reduce(arena[6:])]
+        for fin in fins:
+            fin()
+        assert torch.equal(arena, torch.arange(10, dtype=torch.float32) * 1.5), arena
+        assert "gloo" in cm._AVG_OK      # decided (this gloo may or may not reduce with AVG; the mean is the same)
         # bit-allocation sweep: candidates are dealt round-robin to the ranks, scores gathered everywhere
         from neuroquant_amd.methods import bit_assign as ba
         cands = {f"candidate{i + 1}": [2 + (i + j) % 6 for j in range(7)] for i in range(5)}

@@ -398,7 +398,7 @@ def test_captured_dp_iterations_equal_eager(golden, rehearsal_env, monkeypatch):
 def test_two_processes_gloo_on_gpu(golden, tmp_path, monkeypatch):
     """A REAL world of two: two processes on this GPU, different frames on each, a genuine collective between them (gloo:
     RCCL refuses two ranks on one device) through the product path -- sharded CacheLoader, ops.grad_arena_hook, the
-    asynchronous in-place mean all-reduce of the two arena parts (SUM + scale where the backend has no AVG).  Both replicas
+    asynchronous in-place mean all-reduce of the two arena parts.  Both replicas
     must end bit-identical, and equal the single-process run of the global batch to summation-order tolerance."""
     import subprocess
     import sys
