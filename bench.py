@@ -17,7 +17,7 @@ Scaling modes:
                      iterations/s.
 
 Prints ONE JSON line (rank 0) with
-  `roofline`      dominant kernel of the timed (default-precision, bf16x3) run, HIP-event timed inside every 10th step; the
+  `roofline`      dominant kernel of the timed (default-precision, bf16x3) run, HIP-event timed inside every 10th timed step (the 6th, 16th, ...); the
                   bound (mfma | hbm) is chosen per kernel from its arithmetic intensity against the ridge of its matrix pipe;
   `repeats`       it/s of `--repeats` independent timed runs of the same K steps (`value` = the first);
   `fp32`          the same workload re-timed with exact-fp32 MFMA convolutions (NQ_CONV_PRECISION=fp32) and its roofline;
