@@ -8,7 +8,9 @@
 A step = one phase-2 calibration iteration (AdaRound alpha + regulariser, the 95 % of a 21k run) of HNeRV
 Bunny_1280x640_3M: uint8 frame gather, fake-quant of all 7 layers, decoder forward, L2 loss, full backward,
 d(alpha) + regulariser gradient, Adam.  Inputs are synthetic and resident in HBM before the timed region; weights of the
-timed runs are seeded random-init (iteration cost is value-independent).
+timed (headline) runs are seeded random-init.  The iteration executes the same instructions whatever the values, but its
+DURATION is not value-independent on this chip: the clock the matrix pipe holds depends on how many operand bits toggle
+(MI355X_MICROARCH.md, DVFS), so the same kernels are also timed on real data -- the `trained` object below.
 
 Scaling modes:
   default            weak: per-GPU batch = 2 frames (BASELINE configs[1]; global batch 2N = configs[3] at N = 8), one RCCL
@@ -23,6 +25,11 @@ Prints ONE JSON line (rank 0) with
   `fp32`          the same workload re-timed with exact-fp32 MFMA convolutions (NQ_CONV_PRECISION=fp32) and its roofline;
   `phase1`        the same workload's PHASE-1 iteration (scale learning, 5 % of a run) timed the same way;
   `nerv`          BASELINE configs[2] (NeRV Bunny_1280x640_3M + Hadamard) timed the same way, with its own roofline object;
+  `trained`       the headline iteration timed the same way on the COMMITTED trained checkpoint (38 dB) and the eight real
+                  Bunny crops (tests/golden/hnerv3m_bunny8real_f16.npz, bunny8_640x1280.npz) instead of seeded weights and
+                  synthetic frames: it/s and the dominant kernel's time on the real workload;
+  `uvg`           BASELINE configs[4] shape (HNeRV UVG 960x1920, ~12 M decoder parameters, tools/hnerv_uvg_12m.yaml, synthetic
+                  frames): phase-2 it/s with its own roofline object + the Omega bit-allocation sweep timed per candidate;
   `psnr`          BASELINE configs[0] (the first 8 Bunny frames at 640x1280, iters_w = 50) on the committed trained
                   checkpoint: final PSNR of the CPU oracle, the GPU with exact fp32 and with bf16x3 (bar: within 0.02 dB);
   `cpu_baseline`  the oracle (CPU restatement of the reference path) timed on this box's host cores on that same run
@@ -65,10 +72,15 @@ PROF_PHASE = 5   # ... the 6th, 16th, ... timed step: by then the host is severa
                  # per eager step read 340 instead of 450 it/s)
 
 
+def uvg_12m_config():
+    from neuroquant_amd.utils import get_config
+    return get_config(os.path.join(ROOT, "tools", "hnerv_uvg_12m.yaml"))
+
+
 def build_model(seed=903, workload="hnerv"):
     from neuroquant_amd.models import HNeRV, NeRV
     torch.manual_seed(seed)
-    model = HNeRV(HNERV_3M) if workload == "hnerv" else NeRV(NERV_3M)
+    model = NeRV(NERV_3M) if workload == "nerv" else HNeRV(uvg_12m_config() if workload == "uvg12m" else HNERV_3M)
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():  # decoder: variance-preserving init so activations / gradients have trained-model scale
         for name, p in model.named_parameters():
@@ -156,8 +168,13 @@ def main():
     ap.add_argument("--repeats", type=int, default=3, help="timed runs of K steps; value = the first, all go into `repeats`")
     ap.add_argument("--no-phase1", action="store_true", help="skip the phase-1 (scale learning) timing")
     ap.add_argument("--no-nerv", action="store_true", help="skip the NeRV-3M + Hadamard object (BASELINE configs[2])")
-    ap.add_argument("--workload", choices=("hnerv", "nerv"), default="hnerv",
-                    help="hnerv = the headline config (default); nerv = NeRV-3M + Hadamard (BASELINE configs[2]), no cpu baseline")
+    ap.add_argument("--no-trained", action="store_true", help="skip the `trained` object (headline iteration on the committed "
+                    "checkpoint and the real Bunny crops)")
+    ap.add_argument("--no-uvg", action="store_true", help="skip the `uvg` object (BASELINE configs[4] shape + Omega sweep timing)")
+    ap.add_argument("--uvg-steps", type=int, default=10)
+    ap.add_argument("--workload", choices=("hnerv", "nerv", "uvg12m"), default="hnerv",
+                    help="hnerv = the headline config (default); nerv = NeRV-3M + Hadamard (BASELINE configs[2]); uvg12m = HNeRV UVG "
+                         "960x1920 ~12M (BASELINE configs[4] shape) as the headline line of this run; neither has a cpu baseline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -172,7 +189,13 @@ def main():
     import torch.distributed as dist
     use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("NQ_DP_REHEARSAL"))
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        # NQ_DIST_BACKEND: "nccl" (= RCCL, one rank per GPU: the driver's launch) or "gloo" (rehearsals of the N > 1 command
+        # with several ranks on ONE card -- RCCL refuses two ranks on a device; tests/test_dp_gpu.py)
+        backend = os.environ.get("NQ_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from neuroquant_amd import ops
     from neuroquant_amd.quantization import QuantModel, model_reconstruction
@@ -189,10 +212,43 @@ def main():
         gB = B * world
     K, W = args.steps, args.warmup
     n_frames = max(args.frames // gB * gB, gB)
-    # ---- workload, resident in HBM ----
-    frames_u8 = synthetic_frames(n_frames, 640, 1280, seed=903, device=dev)
-    cache = FrameCache(frames_u8)
-    emb_box = {}
+    # ---- workloads, resident in HBM (built on first use) ----
+    wl_box = {}
+
+    def workload_of(name):
+        """-> dict(arch, hadamard, cache, n, emb, make): frames (uint8 cache), decoder inputs and a factory of fresh models.
+        hnerv / nerv: seeded weights + 132 synthetic 640x1280 frames (the headline); trained: the committed 38 dB HNeRV-3M
+        checkpoint + the eight real Bunny crops; uvg12m: seeded HNeRV UVG-12M + 8 synthetic 960x1920 frames."""
+        if name in wl_box:
+            return wl_box[name]
+        if name == "trained":
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import precision_gate as pg
+            n = max(8 // gB * gB, gB)
+            assert n <= 8, "the real-crop fixture holds 8 frames"
+            cache = FrameCache(pg.bunny_real_640(dev, n))
+            _, emb, _ = pg.load_fixture_checkpoint("hnerv3m_bunny8real_f16.npz", dev)
+            wl = dict(arch="hnerv", hadamard=False, cache=cache, n=n, emb=emb[:n].contiguous(),
+                      make=lambda: pg.load_fixture_checkpoint("hnerv3m_bunny8real_f16.npz", dev)[0])
+        else:
+            hw = (960, 1920) if name == "uvg12m" else (640, 1280)
+            n = max(8 // gB * gB, gB) if name == "uvg12m" else n_frames
+            key = ("frames", hw, n)
+            if key not in wl_box:
+                wl_box[key] = FrameCache(synthetic_frames(n, hw[0], hw[1], seed=903, device=dev))
+            cache = wl_box[key]
+            model = build_model(workload=name).to(dev)
+            with torch.no_grad():
+                if name == "nerv":
+                    emb = model.encode(torch.arange(n, device=dev).float() / n)
+                else:
+                    emb = torch.cat([model.encode(cache.batch(torch.arange(i, min(i + 4, n), device=dev)))
+                                     for i in range(0, n, 4)])
+            del model
+            wl = dict(arch="nerv" if name == "nerv" else "hnerv", hadamard=name == "nerv", cache=cache, n=n, emb=emb,
+                      make=lambda: build_model(workload=name).to(dev))
+        wl_box[name] = wl
+        return wl
 
     def sync():
         if use_dist:
@@ -202,17 +258,10 @@ def main():
     def timed_run(precision, K, W, workload=args.workload, phase1=False):
         """Fresh QuantModel on the seeded weights; W untimed + K timed phase-2 iterations under `precision` (phase1: the
         same count of PHASE-1 iterations -- scales learned through the UAQ fake-quant, reference calib_model.py:119-165)."""
-        nerv = workload == "nerv"
+        wl = workload_of(workload)
+        nerv, arch, cache, emb = wl["hadamard"], wl["arch"], wl["cache"], wl["emb"]
         ops.set_conv_precision(precision)
-        model = build_model(workload=workload).to(dev)
-        if workload not in emb_box:
-            with torch.no_grad():
-                if nerv:
-                    emb_box[workload] = model.encode(torch.arange(n_frames, device=dev).float() / n_frames)
-                else:
-                    emb_box[workload] = torch.cat([model.encode(cache.batch(torch.arange(i, min(i + 4, n_frames), device=dev)))
-                                                   for i in range(0, n_frames, 4)])
-        emb = emb_box[workload]
+        model = wl["make"]()
         qnn = QuantModel(model, hadamard=nerv, weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
         avg_bits = qnn.set_bitwidth(BITS)
         qnn.eval()
@@ -222,7 +271,7 @@ def main():
         steps_total = W + K
         # one "epoch" of W+K+1 batches (shuffled passes over the frames chained): iters = len(loader) gives
         # int(0.05*iters/len) = 0 phase-1 epochs and exactly one phase-2 epoch, for any K
-        loader = CacheLoader(cache, list(range(n_frames)), gB, seed=903, rank=rank, world=world, epoch_batches=steps_total + 1)
+        loader = CacheLoader(cache, list(range(wl["n"])), gB, seed=903, rank=rank, world=world, epoch_batches=steps_total + 1)
         t = {}
         phase = PROF_PHASE if K > PROF_PHASE else 0
 
@@ -252,7 +301,7 @@ def main():
                 t["prof"] = ops.profile_stop() if not os.environ.get("NQ_BENCH_NOPROF") else {}
 
         # iters = 20 * len(loader): int(0.05 * iters / len) = 1 phase-1 epoch of W+K+1 iterations, cut after W+K by max_steps
-        model_reconstruction(qnn, cali_data=emb, gt=loader, arch=workload, batch_size=gB,
+        model_reconstruction(qnn, cali_data=emb, gt=loader, arch=arch, batch_size=gB,
                              iters=(20 if phase1 else 1) * len(loader),
                              hadamard=nerv, warmup=0.0, max_steps=steps_total, step_hook=hook, **FLAGS)
         if "t1" not in t:
@@ -282,7 +331,7 @@ def main():
     # the secondary objects (exact fp32, phase 1, NeRV) describe the single-GPU kernels: N = 1 only -- at N > 1 the line is
     # the data-parallel headline and its repeats, nothing else rides on the collectives
     if world > 1:
-        args.no_fp32 = args.no_phase1 = args.no_nerv = True
+        args.no_fp32 = args.no_phase1 = args.no_nerv = args.no_trained = args.no_uvg = True
     fp32_run = None
     if not args.no_fp32:
         Kf = max(1, min(K, args.fp32_steps))
@@ -291,8 +340,18 @@ def main():
     p1_run = timed_run("bf16x3", K, W, phase1=True) if not args.no_phase1 else None
     # BASELINE configs[2] (NeRV Bunny_1280x640_3M + Hadamard) as a measured object of the same line
     nerv_run = None
-    if not nerv and not args.no_nerv:
+    if args.workload == "hnerv" and not args.no_nerv:
         nerv_run = timed_run("bf16x3", K, W, workload="nerv")
+    # the headline iteration on REAL data: the committed 38 dB checkpoint and the eight real Bunny crops
+    trained_run = None
+    if args.workload == "hnerv" and not args.no_trained and gB <= 8:
+        trained_run = timed_run("bf16x3", K, W, workload="trained")
+    # BASELINE configs[4] shape on one GPU + the Omega sweep, timed per candidate
+    uvg_run = omega = None
+    if args.workload == "hnerv" and not args.no_uvg and not strong:
+        Ku = max(1, min(K, args.uvg_steps))
+        uvg_run = (timed_run("bf16x3", Ku, min(W, 3), workload="uvg12m"), Ku)
+        omega = omega_sweep_timing(workload_of("uvg12m"), dev, B)
 
     if rank != 0:
         if use_dist:
@@ -342,9 +401,49 @@ def main():
         except OSError:
             pass
 
+    trained_obj = None
+    if trained_run is not None:
+        rl, rows_t = roofline_of(trained_run["prof"], trained_run["elapsed"], K, trained_run["t_enq"], "bf16x3", trained_run["prof_steps"])
+        trained_obj = {"value": round(K * per_step_units / trained_run["elapsed"], 3),
+                       "ms_per_step": round(trained_run["elapsed"] / K * 1e3, 3), "steps": K, "unit": "it/s",
+                       "data": "real: tests/golden/hnerv3m_bunny8real_f16.npz (trained, FP 38.07 dB) on tests/golden/bunny8_640x1280.npz",
+                       "dominant_kernel": rl and rl["kernel"], "dominant_kernel_ms": rl and rl["avg_launch_ms"],
+                       "synthetic_dominant_kernel_ms": roofline and roofline["avg_launch_ms"],
+                       "roofline": rl,
+                       "note": "same kernels, same shapes, same K steps as `value`; only the operand VALUES differ (trained "
+                               "weights, real frames): what the clock-vs-toggle-rate dependence of this chip does to the number"}
+        try:
+            with open(os.path.join(ROOT, "gpurun_out", f"bench_kernels_trained_n{world}.json"), "w") as f:
+                json.dump(rows_t, f, indent=1)
+        except OSError:
+            pass
+
+    uvg_obj = None
+    if uvg_run is not None:
+        r, Ku = uvg_run
+        rl, rows_u = roofline_of(r["prof"], r["elapsed"], Ku, r["t_enq"], "bf16x3", r["prof_steps"])
+        conv_gflop = sum(x["gflop_per_launch"] * x["launches"] for x in rows_u) / max(r["prof_steps"], 1)
+        conv_mb = sum(x["mbytes_per_launch"] * x["launches"] for x in rows_u) / max(r["prof_steps"], 1)
+        uvg_obj = {"value": round(Ku * per_step_units / r["elapsed"], 3), "ms_per_step": round(r["elapsed"] / Ku * 1e3, 3),
+                   "steps": Ku, "unit": "it/s",
+                   "config": {"workload": "HNeRV UVG 960x1920, 11.84 M decoder parameters (tools/hnerv_uvg_12m.yaml = the reference's "
+                                          "UVG_1920x960_3M.yaml with dec_in_channel 185; BASELINE configs[4] shape), channel_wise, "
+                                          "bits 6 5 4 5 5 6 6, phase-2 (AdaRound) iteration, synthetic frames",
+                              "per_gpu_batch": B, "avg_bits": r["avg_bits"]},
+                   "roofline": rl,
+                   "conv_gflop_per_step": round(conv_gflop, 1), "conv_mbytes_per_step": round(conv_mb, 1),
+                   "step_tflops": round(conv_gflop * 1e9 / (r["elapsed"] / Ku) / 1e12, 2),
+                   "step_mfma_frac": round(conv_gflop * 1e9 / (r["elapsed"] / Ku) / 1e12 / PEAK_BF16X3_TFLOPS, 4),
+                   "omega_sweep": omega}
+        try:
+            with open(os.path.join(ROOT, "gpurun_out", f"bench_kernels_uvg_n{world}.json"), "w") as f:
+                json.dump(rows_u, f, indent=1)
+        except OSError:
+            pass
+
     # ---- PSNR vs the CPU oracle + CPU baseline timing (BASELINE configs[0]); single GPU, headline workload only ----
     psnr = cpu = None
-    if world == 1 and not args.no_cpu_baseline and not nerv:
+    if world == 1 and not args.no_cpu_baseline and args.workload == "hnerv":
         psnr, cpu = psnr_and_cpu_baseline(dev)
 
     value = K * per_step_units / elapsed
@@ -357,9 +456,10 @@ def main():
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "f32 operands split into bf16 hi+lo, 3 BF16 MFMAs per product, fp32 accumulate (bf16x3); fp32 MFMA on small layers",
         "data": "synthetic",
-        "config": {"workload": ("NeRV Bunny_1280x640_3M + Hadamard" if nerv else "HNeRV Bunny_1280x640_3M")
+        "config": {"workload": {"nerv": "NeRV Bunny_1280x640_3M + Hadamard", "hnerv": "HNeRV Bunny_1280x640_3M",
+                                "uvg12m": "HNeRV UVG 960x1920 ~12M (tools/hnerv_uvg_12m.yaml)"}[args.workload]
                    + ", channel_wise, bits 6 5 4 5 5 6 6, phase-2 (AdaRound) iteration",
-                   "per_gpu_batch": B, "global_batch": gB, "frames": n_frames, "avg_bits": main_run["avg_bits"],
+                   "per_gpu_batch": B, "global_batch": gB, "frames": workload_of(args.workload)["n"], "avg_bits": main_run["avg_bits"],
                    "parallelism": f"dp{world}"},
         "roofline": roofline,
         "repeats": {"values": [round(K * per_step_units / r["elapsed"], 3) for r in [main_run] + more_runs],
@@ -370,12 +470,47 @@ def main():
             "steps": K, "note": "phase-1 iterations (UAQ fake-quant, d(delta), Adam on the scales) of the same workload; a 21k "
                                 "run is 990 of these + 19 998 phase-2 iterations (`value`)"},
         "nerv": nerv_obj,
+        "trained": trained_obj,
+        "uvg": uvg_obj,
         "psnr": psnr,
         "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+
+
+def omega_sweep_timing(wl, dev, B):
+    """The Omega bit-allocation sweep (reference methods/bit_assign.py:57-118, 171-217, 343-372) on the UVG-12M workload, timed
+    per candidate: v'Hv of the two toy candidates over the workload's frames in batches of B (the reference uses the first
+    10 batches; the 8 synthetic frames give 4), double backward through all 7 layers on the HIP kernels."""
+    import copy
+    from neuroquant_amd.methods import bit_assign
+    from neuroquant_amd.quantization import QuantModel
+    model = wl["make"]().eval()
+    cache, n, emb = wl["cache"], wl["n"], wl["emb"]
+    batches = []
+    for i in range(0, n, B):
+        idx = torch.arange(i, min(i + B, n), device=dev)
+        batches.append(dict(img=cache.batch(idx), idx=idx, norm_idx=idx.float() / n))
+    out = {"batches_per_candidate": len(batches), "batch": B, "candidates": {}}
+    for name, bits in bit_assign.hnerv_candidate.items():
+        qn = QuantModel(copy.deepcopy(model), hadamard=False, weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
+        qn.eval()
+        qn.set_bitwidth(bits)
+        qn.set_quant_state(True)
+        with torch.no_grad():
+            qn(emb[:B])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        score = float(bit_assign.sensitivity_criterion("omega", "hnerv", copy.deepcopy(model), qn, batches))
+        torch.cuda.synchronize()
+        out["candidates"][name] = {"bits": bits, "score": score, "seconds": round(time.perf_counter() - t0, 3)}
+        del qn
+    out["seconds_per_candidate"] = round(sum(c["seconds"] for c in out["candidates"].values()) / len(out["candidates"]), 3)
+    del model
+    torch.cuda.empty_cache()
+    return out
 
 
 def psnr_and_cpu_baseline(dev):

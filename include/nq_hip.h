@@ -31,63 +31,67 @@ extern "C" {
 
 typedef void* nq_stream_t; /* hipStream_t */
 
+/* The library is built with -fvisibility=hidden: exactly the entry points declared in this header are exported
+ * (`nm -D --defined-only libnqhip.so` == this file; checked by tests/test_cabi_cpu.py). */
+#define NQ_API __attribute__((visibility("default")))
+
 #define NQ_OK 0
 #define NQ_ERR_INVALID (-1)     /* bad argument (null pointer, non power-of-two length, size <= 0 ...) */
 #define NQ_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are built for */
 #define NQ_ERR_LAUNCH (-3)      /* HIP reported a launch error */
 
-int nq_abi_version(void);
-const char* nq_error_string(int code);
+NQ_API int nq_abi_version(void);
+NQ_API const char* nq_error_string(int code);
 
 /* ---------------------------------------------------------------- quantiser parameter side ---- */
 
 /* UniformAffineQuantizer.init_quantization_scale, 'max' branch (quantizer.py:127-168): per row
  * delta = max((max(x,0)-min(x,0))/(n_levels-1), 1e-8) (division in double, stored fp32),
  * zp = rint(-min/delta).  One value per row is written; a bias / layer-wise tensor is rows=1. */
-int nq_scale_init_max(const float* x, int64_t rows, int64_t row_len, int n_levels, float* delta, float* zp,
+NQ_API int nq_scale_init_max(const float* x, int64_t rows, int64_t row_len, int n_levels, float* delta, float* zp,
                       nq_stream_t stream);
 
 /* UniformAffineQuantizer.forward (quantizer.py:117-119): y = (clamp(rint(x/delta)+zp, 0, L-1) - zp)*delta. */
-int nq_uaq_forward(const float* x, const float* delta, const float* zp, float* y, int64_t rows, int64_t row_len,
+NQ_API int nq_uaq_forward(const float* x, const float* delta, const float* zp, float* y, int64_t rows, int64_t row_len,
                    int per_row, int n_levels, nq_stream_t stream);
 
 /* Backward of the above (round_ste, quantizer.py:53-57): ddelta[row] = sum gy*((xq-zp) -
  * 1{0<=rint(x/delta)+zp<=L-1} * x/delta), overwritten (rows values, or 1 if !per_row); dx (may be NULL; same shape as x)
  * = gy * 1{0<=rint(x/delta)+zp<=L-1}, the straight-through gradient w.r.t. the quantiser input. */
-int nq_uaq_backward(const float* x, const float* gy, const float* delta, const float* zp, float* ddelta, float* dx,
+NQ_API int nq_uaq_backward(const float* x, const float* gy, const float* delta, const float* zp, float* ddelta, float* dx,
                     int64_t rows, int64_t row_len, int per_row, int n_levels, nq_stream_t stream);
 
 /* AdaRoundQuantizer.__init__/init_alpha (quantizer.py:264-265, 305-314): delta/zp through an fp16 round
  * trip, alpha = -log((zeta-gamma)/(frac(x/delta)-gamma) - 1).  delta_out/zp_out have the size of delta_in. */
-int nq_adaround_init(const float* x, const float* delta_in, const float* zp_in, float* delta_out, float* zp_out,
+NQ_API int nq_adaround_init(const float* x, const float* delta_in, const float* zp_in, float* delta_out, float* zp_out,
                      float* alpha, int64_t rows, int64_t row_len, int per_row, nq_stream_t stream);
 
 /* AdaRoundQuantizer.forward 'learned_hard_sigmoid' (quantizer.py:288-300): soft!=0 -> floor(x/delta)+h(alpha),
  * else floor(x/delta)+1{alpha>=0}; xq (may be NULL) receives the clamped integer grid value x_quant. */
-int nq_adaround_forward(const float* x, const float* alpha, const float* delta, const float* zp, float* y, float* xq,
+NQ_API int nq_adaround_forward(const float* x, const float* alpha, const float* delta, const float* zp, float* y, float* xq,
                         int64_t rows, int64_t row_len, int per_row, int n_levels, int soft, nq_stream_t stream);
 
 /* d/dalpha of the soft forward, plus (reg_weight != 0) the gradient of the rounding regulariser
  * reg_weight * sum(1 - |2h(alpha)-1|^reg_b) (calib_model.py:39-47).  dalpha is overwritten. */
-int nq_adaround_backward(const float* x, const float* gy, const float* alpha, const float* delta, const float* zp,
+NQ_API int nq_adaround_backward(const float* x, const float* gy, const float* alpha, const float* delta, const float* zp,
                          float* dalpha, int64_t rows, int64_t row_len, int per_row, int n_levels, float reg_weight,
                          float reg_b, nq_stream_t stream);
 
 /* Value of the regulariser over one alpha tensor: out[0] (+)= weight*sum(1-|2h-1|^b) (calib_model.py:45).
  * ws: >= nq_reduce_ws_floats(n) floats of scratch; accumulate!=0 adds to out[0]. Deterministic. */
-int64_t nq_reduce_ws_floats(int64_t n);
-int nq_round_loss(const float* alpha, int64_t n, float b, float weight, float* ws, float* out, int accumulate,
+NQ_API int64_t nq_reduce_ws_floats(int64_t n);
+NQ_API int nq_round_loss(const float* alpha, int64_t n, float b, float weight, float* ws, float* out, int accumulate,
                   nq_stream_t stream);
 
 /* Gradient of the regulariser alone: dalpha (+)= gscale[0] * weight * d/dalpha sum(1-|2h-1|^b); gscale is a
  * device scalar (the upstream gradient of the loss term) or NULL for 1. */
-int nq_round_loss_backward(const float* alpha, int64_t n, float b, float weight, const float* gscale, float* dalpha,
+NQ_API int nq_round_loss_backward(const float* alpha, int64_t n, float b, float weight, const float* gscale, float* dalpha,
                            int accumulate, nq_stream_t stream);
 
 /* torch.optim.Adam single-tensor step, no weight decay / amsgrad (used by calib_model.py:134, 195):
  * m += (g-m)*(1-beta1); v = v*beta2 + (1-beta2)*g*g; p -= step_size * m / (sqrt(v)/bc2_sqrt + eps),
  * step_size = lr/(1-beta1^t), bc2_sqrt = sqrt(1-beta2^t) computed by the host in double. */
-int nq_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float beta1, float beta2,
+NQ_API int nq_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float step_size, float beta1, float beta2,
                  float eps, float bc2_sqrt, nq_stream_t stream);
 
 /* ---- multi-tensor variants: ONE launch for all layers (the per-iteration parameter side is 14 small tensors; 42
@@ -129,17 +133,17 @@ typedef struct nq_ada_adam_seg {
   int per_row, n_levels;
   float reg_weight;
 } nq_ada_adam_seg;
-int nq_adaround_adam_multi(const nq_ada_adam_seg* segs, int nseg, float reg_b, float step_size, float beta1, float beta2, float eps,
+NQ_API int nq_adaround_adam_multi(const nq_ada_adam_seg* segs, int nseg, float reg_b, float step_size, float beta1, float beta2, float eps,
                            float bc2_sqrt, const float* dyn, nq_stream_t stream);
-int nq_adaround_forward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream);
+NQ_API int nq_adaround_forward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream);
 /* The UAQ fake-quant (nq_uaq_forward) / its d(delta) (nq_uaq_backward without dx) for several tensors in one launch:
  * phase 1 of the calibration (calib_model.py:119-165).  Uses x, gy (backward), delta, zp, out (forward: y; backward:
  * d(delta), one value per reduction row), rows, row_len, per_row, n_levels of nq_ada_seg; alpha / soft / reg_weight are
  * ignored.  Bit-identical to the single-tensor entry points. */
-int nq_uaq_forward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream);
-int nq_uaq_backward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream);
-int nq_adaround_backward_multi(const nq_ada_seg* segs, int nseg, float reg_b, nq_stream_t stream);
-int nq_adam_step_multi(const nq_adam_seg* segs, int nseg, float step_size, float beta1, float beta2, float eps,
+NQ_API int nq_uaq_forward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream);
+NQ_API int nq_uaq_backward_multi(const nq_ada_seg* segs, int nseg, nq_stream_t stream);
+NQ_API int nq_adaround_backward_multi(const nq_ada_seg* segs, int nseg, float reg_b, nq_stream_t stream);
+NQ_API int nq_adam_step_multi(const nq_adam_seg* segs, int nseg, float step_size, float beta1, float beta2, float eps,
                        float bc2_sqrt, nq_stream_t stream);
 
 /* ---- captured iterations (hipGraph): what changes from one calibration iteration to the next is the batch (frame
@@ -148,21 +152,21 @@ int nq_adam_step_multi(const nq_adam_seg* segs, int nseg, float step_size, float
  * fixed slots (cur_idx: B int64 frame indices; cur_scal: nscal floats) and increments *step, and the _dyn variants read
  * their scalars from cur_scal = {reg_b, regulariser gate (0 or 1), lr/(1-beta1^t), sqrt(1-beta2^t)} instead of from
  * host arguments -- same values, same arithmetic, so a replayed iteration is bit-identical to an eagerly launched one. */
-int nq_step_prologue(const int64_t* order, const float* scal, int* step, int64_t* cur_idx, float* cur_scal, int B, int nscal,
+NQ_API int nq_step_prologue(const int64_t* order, const float* scal, int* step, int64_t* cur_idx, float* cur_scal, int B, int nscal,
                      nq_stream_t stream);
 /* The same, plus the batch's rows of a table gathered in the same launch: out[t] = table[cur_idx[t]] (row_len floats each),
  * i.e. the decoder inputs cali_data[idx] (calib_model.py:150, :201) without a separate index_select launch. */
-int nq_step_prologue_gather(const int64_t* order, const float* scal, int* step, int64_t* cur_idx, float* cur_scal, int B, int nscal,
+NQ_API int nq_step_prologue_gather(const int64_t* order, const float* scal, int* step, int64_t* cur_idx, float* cur_scal, int B, int nscal,
                             const float* table, int64_t table_rows, int64_t row_len, float* out, nq_stream_t stream);
-int nq_adaround_backward_multi_dyn(const nq_ada_seg* segs, int nseg, const float* dyn, nq_stream_t stream);
-int nq_adam_step_multi_dyn(const nq_adam_seg* segs, int nseg, const float* dyn, float beta1, float beta2, float eps,
+NQ_API int nq_adaround_backward_multi_dyn(const nq_ada_seg* segs, int nseg, const float* dyn, nq_stream_t stream);
+NQ_API int nq_adam_step_multi_dyn(const nq_adam_seg* segs, int nseg, const float* dyn, float beta1, float beta2, float eps,
                            nq_stream_t stream);
 
 /* Orthonormal Walsh-Hadamard transform along the middle axis (hadamard_along_channel_weight,
  * quant_layer.py:16-22, with the zero-padding of :45-49 and the slice of :71 folded in):
  * x is [outer][n_in][inner] (read as zero for index >= n_in), y is [outer][n_out][inner], transform
  * length n = 2^k <= 1024, n_in <= n, n_out <= n.  x and y must not alias. */
-int nq_fwht(const float* x, float* y, int64_t outer, int n, int64_t inner, int n_in, int n_out, nq_stream_t stream);
+NQ_API int nq_fwht(const float* x, float* y, int64_t outer, int n, int64_t inner, int n_in, int n_out, nq_stream_t stream);
 
 /* nq_fwht for several tensors in ONE launch (all layers of a decoder); `segs` is a host array, the pointers inside are
  * device pointers; fields as the arguments of nq_fwht (same arithmetic, bit-identical results). */
@@ -172,7 +176,7 @@ typedef struct nq_fwht_seg {
   int64_t outer, inner;
   int n, n_in, n_out;
 } nq_fwht_seg;
-int nq_fwht_multi(const nq_fwht_seg* segs, int nseg, nq_stream_t stream);
+NQ_API int nq_fwht_multi(const nq_fwht_seg* segs, int nseg, nq_stream_t stream);
 
 /* ---------------------------------------------------------------- convolution side ------------ */
 
@@ -180,7 +184,7 @@ int nq_fwht_multi(const nq_fwht_seg* segs, int nseg, nq_stream_t stream);
  *   wt_fwd [krows_fwd][ld_fwd]: row (ci*k+kh)*k+kw, column co            (forward)
  *   wt_bwd [krows_bwd][ld_bwd]: row (co*k+kh)*k+kw, column ci, taps flipped (data gradient)
  * rows/columns beyond the real extents are written as zero.  Either output may be NULL. */
-int nq_weight_layouts(const float* w, float* wt_fwd, float* wt_bwd, int Cout, int Cin, int k, int krows_fwd,
+NQ_API int nq_weight_layouts(const float* w, float* wt_fwd, float* wt_bwd, int Cout, int Cin, int k, int krows_fwd,
                       int ld_fwd, int krows_bwd, int ld_bwd, nq_stream_t stream);
 
 /* nq_weight_layouts for several layers in ONE launch (the per-layer form is launch-bound); `segs` is a host array, the
@@ -191,10 +195,10 @@ typedef struct nq_wl_seg {
   float* wt_bwd;
   int Cout, Cin, k, krows_fwd, ld_fwd, krows_bwd, ld_bwd;
 } nq_wl_seg;
-int nq_weight_layouts_multi(const nq_wl_seg* segs, int nseg, nq_stream_t stream);
+NQ_API int nq_weight_layouts_multi(const nq_wl_seg* segs, int nseg, nq_stream_t stream);
 
 /* Padded operand sizes the conv kernels expect for a (Cin -> Cout, k) convolution. */
-int nq_conv_operand_dims(int Cin, int Cout, int k, int* krows, int* ld);
+NQ_API int nq_conv_operand_dims(int Cin, int Cout, int k, int* krows, int* ld);
 
 /* Implicit-GEMM convolution on the fp32 MFMA pipe (replaces F.conv2d in QuantModule.forward,
  * quant_layer.py:80, fused with what follows it in the decoder):
@@ -215,9 +219,9 @@ int nq_conv_operand_dims(int Cin, int Cout, int k, int* krows, int* ld);
 #define NQ_EPI_DGRAD_GELU 4 /* data gradient: y = conv * zprev, zprev (B,Cout,H,W) = the z a NQ_EPI_PS_GELU forward saved
                              * (= gelu' of the pre-activation), stored PixelUnshuffle(r)-ed, i.e. as the
                              * (B,Cout*r*r,H/r,W/r) output gradient of the convolution below */
-int64_t nq_conv_forward_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
+NQ_API int64_t nq_conv_forward_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
 /* in_gelu != 0: x holds pre-activations and exact GELU is applied while the input tile is staged. */
-int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y, float* z, float* ws, int B, int Cin, int H,
+NQ_API int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y, float* z, float* ws, int B, int Cin, int H,
                     int W, int Cout, int k, int krows, int ld, int r, int epilogue, int in_gelu, const float* zprev,
                     nq_stream_t stream);
 
@@ -231,10 +235,10 @@ int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y
  *                           (then Cin/Cout are those of the gradient convolution: Cin = w's C_out, Cout = w's C_in)
  *   nq_conv_forward3      : same contract as nq_conv_forward (epilogues, zprev); ws = nq_conv_forward3_ws_floats
  *                           floats (0 -> may be NULL): deep low-resolution layers are split over channel chunks */
-int nq_conv3_supported(int B, int Cin, int H, int W, int Cout, int k);
-int64_t nq_conv_forward3_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
-int64_t nq_conv3_weight_bytes(int Cin, int Cout, int k);
-int nq_weight_layout3(const float* w, void* wt3, int Cin, int Cout, int k, int transposed, nq_stream_t stream);
+NQ_API int nq_conv3_supported(int B, int Cin, int H, int W, int Cout, int k);
+NQ_API int64_t nq_conv_forward3_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
+NQ_API int64_t nq_conv3_weight_bytes(int Cin, int Cout, int k);
+NQ_API int nq_weight_layout3(const float* w, void* wt3, int Cin, int Cout, int k, int transposed, nq_stream_t stream);
 /* several operands (all layers, forward and data-gradient) in ONE launch; `segs` is a host array, pointers inside are
  * device pointers; Cin/Cout/transposed per segment as for nq_weight_layout3 */
 typedef struct nq_wl3_seg {
@@ -242,32 +246,32 @@ typedef struct nq_wl3_seg {
   void* wt3;
   int Cin, Cout, k, transposed;
 } nq_wl3_seg;
-int nq_weight_layout3_multi(const nq_wl3_seg* segs, int nseg, nq_stream_t stream);
-int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* y, float* z, const float* zprev, float* ws, int B,
+NQ_API int nq_weight_layout3_multi(const nq_wl3_seg* segs, int nseg, nq_stream_t stream);
+NQ_API int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* y, float* z, const float* zprev, float* ws, int B,
                      int Cin, int H, int W, int Cout, int k, int r, int epilogue, nq_stream_t stream);
 
 /* bf16x3 variant of nq_conv_wgrad (same contract, x_gelu not offered): */
-int nq_conv_wgrad3_supported(int B, int Cin, int H, int W, int Cout, int k);
-int64_t nq_conv_wgrad3_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
+NQ_API int nq_conv_wgrad3_supported(int B, int Cin, int H, int W, int Cout, int k);
+NQ_API int64_t nq_conv_wgrad3_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
 /* The launch plan nq_conv_wgrad3 will use for this shape (pure host function): MT = 16*mi channels x NT = 64*ni columns per
  * workgroup, nsplit K-splits, pc != 0 -> the 8-wave producer/consumer kernel (32-bit buffer offsets: only for operands
  * below 2 GiB), pc == 0 -> the 4-wave kernel (64-bit pointers). */
-int nq_conv_wgrad3_plan(int B, int Cin, int H, int W, int Cout, int k, int* mi, int* ni, int* nsplit, int* pc);
-int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+NQ_API int nq_conv_wgrad3_plan(int B, int Cin, int H, int W, int Cout, int k, int* mi, int* ni, int* nsplit, int* pc);
+NQ_API int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                    int k, nq_stream_t stream);
 /* The same weight gradient dw (Cout,Cin,k,k) for a convolution with very FEW output channels (the 3-channel head, HNeRV.py:42)
  * by exchanged operand roles: R[ci][(co,tap)] = sum_p x[ci][p] * dy[co][p+tap] is the weight gradient of the convolution
  * dy -> x-channels and dW[co][ci][tap] = R[ci][co][k*k-1-tap]; the big tensor x is then the un-shifted GEMM operand read
  * exactly once.  ws: nq_conv_wgrad3_ws_floats(B, Cout, H, W, Cin, k) floats (the exchanged problem).  No bias gradient
  * (use nq_channel_sum on dy). */
-int nq_conv_wgrad3_swapped(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int H, int W, int Cout, int k,
+NQ_API int nq_conv_wgrad3_swapped(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int H, int W, int Cout, int k,
                            nq_stream_t stream);
 
 /* Weight + bias gradient of the same convolution: dw (Cout,Cin,k,k), db (Cout) (db may be NULL),
  * from x (B,Cin,H,W) and dy (B,Cout,H,W).  ws: scratch of >= nq_conv_wgrad_ws_floats(...) floats.
  * x_gelu != 0: x holds pre-activations, exact GELU is applied while staging.  Deterministic (fixed split-K order). */
-int64_t nq_conv_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
-int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+NQ_API int64_t nq_conv_wgrad_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
+NQ_API int nq_conv_wgrad(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                   int k, int x_gelu, nq_stream_t stream);
 
 /* Deferred slab reduction (round 3).  The weight-gradient kernels above split K over workgroups into slabs and finish with a
@@ -285,30 +289,30 @@ typedef struct nq_wgr_seg {
   int swap_kk;           /* > 0: role-swapped problem, dw[ci][co][kk-1-tap] = R[co][ci][tap] (nq_conv_wgrad3_swapped) */
   int sg;                /* split groups per output (1, 4 or 16): fixes the summation order */
 } nq_wgr_seg;
-int nq_conv_wgrad3_slabs(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+NQ_API int nq_conv_wgrad3_slabs(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                          int k, nq_wgr_seg* seg, nq_stream_t stream);
-int nq_conv_wgrad3_swapped_slabs(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int H, int W, int Cout,
+NQ_API int nq_conv_wgrad3_swapped_slabs(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int H, int W, int Cout,
                                  int k, nq_wgr_seg* seg, nq_stream_t stream);
-int nq_conv_wgrad_slabs(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+NQ_API int nq_conv_wgrad_slabs(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                         int k, int x_gelu, nq_wgr_seg* seg, nq_stream_t stream);
-int nq_wgrad_reduce_multi(const nq_wgr_seg* segs, int nseg, nq_stream_t stream);
+NQ_API int nq_wgrad_reduce_multi(const nq_wgr_seg* segs, int nseg, nq_stream_t stream);
 
 /* Backward of PixelShuffle(r)+GELU: dconv (B,C*r*r,H,W) = unshuffle(da * z), da and z (B,C,H*r,W*r), z = the saved
  * derivative output of a NQ_EPI_PS_GELU forward. */
-int nq_ps_gelu_backward(const float* da, const float* z, float* dconv, int B, int C, int H, int W, int r,
+NQ_API int nq_ps_gelu_backward(const float* da, const float* z, float* dconv, int B, int C, int H, int W, int r,
                         nq_stream_t stream);
 
 /* Backward of OutImg 'tanh': dconv = dimg * 0.5 * (1 - t^2), t = 2*img - 1. */
-int nq_tanh_out_backward(const float* dimg, const float* img, float* dconv, int64_t n, nq_stream_t stream);
+NQ_API int nq_tanh_out_backward(const float* dimg, const float* img, float* dconv, int64_t n, nq_stream_t stream);
 
 /* lp_loss p=2 (quantizer.py:66-71): loss[0] = sum_{b,c,h,w}(pred-tgt)^2 / (B*H*W); dpred (may be NULL) =
  * 2*(pred-tgt)/(B*H*W) * gscale.  ws: >= nq_reduce_ws_floats(n) floats.  Deterministic. */
-int nq_l2_loss(const float* pred, const float* tgt, float* loss, float* dpred, float* ws, int64_t n, int64_t mean_count,
+NQ_API int nq_l2_loss(const float* pred, const float* tgt, float* loss, float* dpred, float* ws, int64_t n, int64_t mean_count,
                float gscale, nq_stream_t stream);
 
 /* Per-channel sums of an NCHW tensor, out[c] = sum_{b,h,w} x[b][c][h][w] (bias gradient of a convolution);
  * ws: >= 512*C floats.  Deterministic. */
-int nq_channel_sum(const float* x, float* out, float* ws, int B, int C, int64_t HW, nq_stream_t stream);
+NQ_API int nq_channel_sum(const float* x, float* out, float* ws, int B, int C, int64_t HW, nq_stream_t stream);
 
 /* nq_l2_loss + nq_tanh_out_backward + nq_channel_sum of a tanh-headed decoder in one pass over the image (the tail of
  * calib_model.py:219-226 for OutImg 'tanh', models/_layers.py): loss[0] as nq_l2_loss (bit-identical), dconv (B,C,H,W) =
@@ -317,16 +321,16 @@ int nq_channel_sum(const float* x, float* out, float* ws, int B, int C, int64_t 
  * frame cache `cache_u8` (N,C,H,W) with frame indices idx[B] (tgt = cache[idx]/255, videosets/datasets.py:19-24);
  * exactly one of the two is non-NULL.  ws: >= 2*nq_reduce_ws_floats(B*C*HW) floats.  NQ_ERR_UNSUPPORTED unless
  * HW % 4096 == 0 (callers then use the three separate entry points).  Deterministic. */
-int nq_l2_loss_tanh_head(const float* pred, const float* tgt, const uint8_t* cache_u8, const int64_t* idx, float* loss,
+NQ_API int nq_l2_loss_tanh_head(const float* pred, const float* tgt, const uint8_t* cache_u8, const int64_t* idx, float* loss,
                          float* dconv, float* db, float* ws, int B, int C, int64_t HW, int64_t mean_count, float gscale,
                          nq_stream_t stream);
 
 /* Per-frame PSNR pieces (utils.py:148-151): sse[f] = sum over one frame of (out-gt)^2, frames of frame_len floats. */
-int nq_frame_sse(const float* out, const float* gt, float* sse, int64_t frames, int64_t frame_len, nq_stream_t stream);
+NQ_API int nq_frame_sse(const float* out, const float* gt, float* sse, int64_t frames, int64_t frame_len, nq_stream_t stream);
 
 /* Frame gather: dst[i] = float(src_u8[idx[i]]) / 255 for frames of frame_len bytes (videosets/datasets.py:19-24);
  * idx is a device int64 array of n entries. */
-int nq_gather_frames_u8(const uint8_t* src, const int64_t* idx, float* dst, int64_t n, int64_t frame_len,
+NQ_API int nq_gather_frames_u8(const uint8_t* src, const int64_t* idx, float* dst, int64_t n, int64_t frame_len,
                         nq_stream_t stream);
 
 #ifdef __cplusplus

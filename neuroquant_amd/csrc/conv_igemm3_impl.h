@@ -68,12 +68,6 @@ struct Conv3Args {
 #ifndef NQ_IG3_ABL
 #define NQ_IG3_ABL 0
 #endif
-#ifndef NQ_IG3_R4MIN
-#define NQ_IG3_R4MIN 5   // smallest MI that keeps its weights in a ring of four LDS buffers (one barrier per two k-steps)
-#endif
-#ifndef NQ_IG3_WDMA
-#define NQ_IG3_WDMA 1   // weights by LDS-DMA (buffer_load_dwordx4 ... lds) into a ring of four buffers, three k-steps ahead
-#endif
 #ifndef NQ_IG3_OCC3_DEFAULT
 #define NQ_IG3_OCC3_DEFAULT 40
 #endif
@@ -140,16 +134,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 
   extern __shared__ __attribute__((aligned(16))) u32x4 smem[];
   u32x4* const patch0 = smem;                  // 1 buffer of PATCH_U4 (re-filled between two barriers per chunk)
-  // R4: ring of 4 weight buffers with one barrier per TWO k-steps (measured in one process, per-step barrier -> ring: the
-  // 80-channel tile -10 %, the 48/64-channel tiles +2..3 % -- so only MI = 5 takes it); else 2 buffers, barrier per step
-  constexpr bool WDMA = NQ_IG3_WDMA != 0 && MI >= 3;   // (narrow tiles: see below)
-  constexpr bool R4 = !WDMA && (MI >= NQ_IG3_R4MIN);
+  // Tiles of >= 48 channels fetch their weights by LDS-DMA (buffer_load_dwordx4 ... lds) into a ring of four buffers, three
+  // k-steps ahead; the 16-/32-channel tiles stage them through two register sets into two buffers, one barrier per step.
+  // (Round 2's register-staged ring of four for the 80-channel tile was superseded by the DMA ring and is gone.)
+  constexpr bool WDMA = MI >= 3;
   // WDMA ring: NB buffers, k-step g+D fetched during step g (D = NB - 1): 3 steps of ~1 us cover an L2 round trip.
   // The 16-/32-channel tiles keep the register staging: their k-steps hold 12-24 MFMAs, and one LDS-DMA piece per step
   // costs a wave more issue time than a load + ds_write pair (NeRV's 96 -> 24 data gradient at 320x640: 90 us with
   // registers at three waves per SIMD, 97 us with a ring of four, 103 us with a ring of eight).
   constexpr int NB = 4, WD = NB - 1;
-  constexpr int WMASK = WDMA ? NB - 1 : (R4 ? 3 : 1);
+  constexpr int WMASK = WDMA ? NB - 1 : 1;
   // WDMA: the weight operand is already the LDS image ([k-step][plane][kq][MT] 16-byte units, bf16 hi / lo split done by
   // nq_weight_layout3), so a k-step's W_U4 units go global -> LDS directly: WPT `buffer_load_dwordx4 ... lds` per wave
   // (1 KiB each: wave-uniform LDS base + lane * 16), no registers, no ds_write, and a prefetch distance of THREE k-steps
@@ -339,23 +333,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     NQ3_BARRIER_LDS()
   } else {
   NQ3_STORE_W(wvA, wl0)
-  if constexpr (R4) {
-    if (G > 1) {
-      NQ3_STORE_W(wvB, wl0 + W_U4)
-    }
-    NQ3_LOAD_W(wvA, 2)
-    NQ3_LOAD_W(wvB, 3)
-  }
   __syncthreads();
   }
 
-  // Weight pipeline, R4: k-step g reads LDS buffer g & 3.  During step g (in the middle of its MFMA block) register set g & 1,
-  // which holds the weights of step g+2 (loaded two steps ago), is published into buffer (g+2) & 3 and re-armed with the
-  // loads of step g+4.  With a ring of FOUR buffers one barrier per TWO k-steps is enough: a barrier follows every odd
-  // step of a chunk (and its last step), which always puts one between the publication of a buffer (step g-2) and its use
-  // (step g), and one between the last reads of a buffer (step g-4) and its re-publication (step g-2).
-  // !R4: LDS buffer g & 1 holds step g, register set (g+1) & 1 holds step g+1 and is published during step g, the loads of
-  // step g+2 are issued into the other set at the start of step g; a barrier after every step.
+  // Register-staged weight pipeline (!WDMA): LDS buffer g & 1 holds step g, register set (g+1) & 1 holds step g+1 and is
+  // published during step g, the loads of step g+2 are issued into the other set at the start of step g; a barrier after
+  // every step.
   // one chunk; PAR = parity of its first global step
   auto run_chunk = [&](auto par_c, auto tail_c, int ch) {
     constexpr int PAR = decltype(par_c)::value;
@@ -373,7 +356,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       // nothing that was not needed anyway.
       constexpr bool LATE_DMA = WDMA && !TAIL && st == NST - 1;
       if constexpr (WDMA && !LATE_DMA) NQ3_DMA_W(g + WD)
-      if constexpr (!WDMA && !R4 && NQ_IG3_ABL != 9 && NQ_IG3_ABL != 10) {   // ablations 9 / 10: the weights of the first steps for all
+      if constexpr (!WDMA && NQ_IG3_ABL != 9 && NQ_IG3_ABL != 10) {   // ablations 9 / 10: the weights of the first steps for all
         if constexpr (gp == 0) {
           NQ3_LOAD_W(wvA, g + 2)
         } else {
@@ -472,20 +455,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
           // publish the next weights in the MIDDLE of the MFMA block (the LDS write latency is covered by the remaining
           // MFMAs instead of sitting in front of the barrier)
           if constexpr (NQ_IG3_ABL == 9 || NQ_IG3_ABL == 10 || WDMA) {
-          } else if constexpr (R4) {   // step g+2 from set g & 1, which is then re-armed with the loads of step g+4
-            if (g + 2 < G) {
-              u32x4* wdst = wl0 + ((g + 2) & 3) * W_U4;
-              if constexpr (gp == 0) {
-                NQ3_STORE_W(wvA, wdst)
-              } else {
-                NQ3_STORE_W(wvB, wdst)
-              }
-            }
-            if constexpr (gp == 0) {
-              NQ3_LOAD_W(wvA, g + 4)
-            } else {
-              NQ3_LOAD_W(wvB, g + 4)
-            }
           } else {              // step g+1 (loaded one step ago) from set (g+1) & 1
             if (g + 1 < G) {
               u32x4* wdst = wl0 + (gp ^ 1) * W_U4;
@@ -524,7 +493,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
           NQ3_STORE_PATCH(patch0)
         }
       }
-      if constexpr (!R4 || (st & 1) != 0 || st == NSTC - 1) __syncthreads();
+      __syncthreads();
       }
     });
   };
@@ -783,8 +752,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 template <int MI>
 int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
   constexpr int MT = 16 * MI;
-  size_t lds = (size_t)(PATCH_U4 + (MI >= NQ_IG3_R4MIN ? 4 : 2) * 2 * 4 * MT) * 16;   // patch + weight buffers (ring of 4 for MI = 5)
-  if (NQ_IG3_WDMA && MI >= 3) lds = (size_t)(PATCH_U4 + 4 * (2 * 4 * MT) + ((2 * 4 * MT + 255) / 256 * 256 - 2 * 4 * MT)) * 16;  // ring of 4 + dump area
+  size_t lds = (size_t)(PATCH_U4 + 2 * 2 * 4 * MT) * 16;   // patch + two weight buffers (register-staged tiles)
+  if (MI >= 3) lds = (size_t)(PATCH_U4 + 4 * (2 * 4 * MT) + ((2 * 4 * MT + 255) / 256 * 256 - 2 * 4 * MT)) * 16;  // DMA ring of 4 + dump area
   Conv3Args a = a_in;
   a.lds_epi = 0;
   if (a.epi == NQ_EPI_DGRAD_GELU && a.nsplit == 1 && MI <= 4) {   // 4 waves x [MT][64] floats for the wide epilogue

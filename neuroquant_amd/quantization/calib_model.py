@@ -135,6 +135,14 @@ class _Layer:
 _AVG_OK = {}    # backend name -> the backend reduces with ReduceOp.AVG (RCCL does, this image's gloo too; older gloo refuses it)
 
 
+def _avg_unsupported(err):
+    """True for the error a backend raises when it has no ReduceOp.AVG ("AVG is only available with the NCCL backend",
+    "Cannot use ReduceOp.AVG with Gloo", "unsupported reduce op" ...).  Anything else -- a communicator fault, a timeout,
+    a wrong device -- is NOT swallowed: with RCCL an asynchronous collective can also raise RuntimeError for those."""
+    msg = str(err).lower()
+    return "avg" in msg or "reduceop" in msg or "reduce op" in msg or "unsupported reduction" in msg
+
+
 def _mean_all_reduce(t):
     """Asynchronous in-place mean of `t` over the ranks; -> a function that completes it (the compute stream waits for the
     collective -- no host synchronisation with RCCL).  ReduceOp.AVG where the backend has it (RCCL: the division happens
@@ -146,7 +154,9 @@ def _mean_all_reduce(t):
             w = dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
             _AVG_OK[be] = True
             return w.wait
-        except (RuntimeError, ValueError, NotImplementedError):
+        except (RuntimeError, ValueError, NotImplementedError) as err:
+            if not _avg_unsupported(err):
+                raise
             _AVG_OK[be] = False
     w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
     scale = 1.0 / dist.get_world_size()
@@ -212,8 +222,9 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
     # tables; nq_step_prologue copies the current row into fixed slots that the kernels read (same values and arithmetic
     # as the host-argument path: replays are bit-identical to eager launches, tested).  Iterations that log (every 500,
     # the reference's float() sync), that are HIP-event profiled, or the first three of a phase run eagerly through the
-    # SAME body.  Off for: recorder / probe (tests that inspect every iteration), data-parallel runs (the in-place RCCL
-    # all-reduce sits in the middle of the backward pass), generic `gt` iterables, NQ_GRAPH=0.
+    # SAME body.  Off for: recorder / probe (tests that inspect every iteration), generic `gt` iterables, NQ_GRAPH=0.
+    # Data-parallel runs replay the staged form below (three graphs with the collectives between them) when NQ_DP_GRAPH=1
+    # and run eagerly otherwise.
     use_graph = (os.environ.get("NQ_GRAPH", "1") != "0" and device.type == 'cuda' and recorder is None
                  and probe is None and hasattr(gt, 'epoch_indices') and hasattr(gt, 'cache'))
     # Data-parallel runs (round 3): the iteration is captured as up to THREE graphs -- everything up to the first complete

@@ -26,6 +26,9 @@ Fixtures (what each one pins; reference file:line):
   traj_nerv_had.npz  tiny NeRV + Hadamard: same (FWHT via stub -> "parity unpinned" at the transform)
   config1_hnerv3m.npz  BASELINE configs[0] at FULL size with the real reference: HNeRV-3M (trained checkpoint
                      hnerv3m_bunny8_f16.npz), 8 frames of 640x1280, 48 iterations: loss log + PSNRs     calib_model.py:92-240
+  config2_nerv3m_hadamard.npz   BASELINE configs[2] at FULL size with the real reference: NeRV-3M + --hadamard (trained
+                     checkpoint nerv3m_bunny8real_f16.npz), the 8 real 640x1280 crops, 48 iterations            quant_layer.py:44-49, 70-71
+  config1_hnerv3m_hadamard.npz  the same for HNeRV-3M + --hadamard on hnerv3m_bunny8real_f16.npz                 calib_model.py:170-191
   omega.npz          tiny HNeRV (checkpoint of traj_hnerv.npz): get_perturbation() and the reference's own
                      sensitivity_criterion ('omega' = v'Hv by double backward, 'fisher_diag') for the two toy
                      candidates of bit_assign.py:27-30                          bit_assign.py:57-217
@@ -667,6 +670,90 @@ def gen_config1():
     save("config1_hnerv3m.npz", **out)
 
 
+NERV_3M = dict(crop_h=640, crop_w=1280, diff_enc=False, base=1.25, level=80, channel_reduce=2, channel_lbound=24,
+               dec_in_channel=145, dec_kernels=[3, 3, 3, 3, 3], dec_strides=[5, 4, 4, 2, 2], dec_norm="none",
+               dec_acts="gelu", out_bias="tanh")   # configs/NeRV/Bunny_1280x640_3M.yaml:3-20
+
+
+def gen_fullsize_hadamard(name, arch, ckpt_name):
+    """Round 4: the Hadamard path at FULL size against the REAL reference.  `arch` 'nerv': BASELINE
+    configs[2] = NeRV Bunny_1280x640_3M with --hadamard on the checkpoint fixture nerv3m_bunny8real_f16.npz (this repo's
+    trainer on one MI355X, the eight real Bunny crops, FP 33.4 dB; reference log: FP 33.25 dB); 'hnerv': HNeRV-3M with
+    --hadamard on hnerv3m_bunny8real_f16.npz (FP 38.07 dB).  Frames = bunny8_640x1280.npz (the reference's center crop),
+    --precision 6 5 4 5 5 6 6, batch 2, iters_w = 50 -> 48 phase-2 iterations of the reference's own model_reconstruction
+    (quant_layer.py:44-49, 70-71: pad C_in to 2^k, transform, quantise in the transform domain, transform back, slice;
+    calib_model.py:170-191: alpha on every one of the C_pad coefficients).  Stored: batch order, 48-entry loss log, PSNRs
+    (FP / w/o opt / w/ opt), the initial scales on the padded transform-domain weights, the final hard-rounding masks.
+    The butterflies run in _ref_stubs._fwht_normalized (pip hadamard_transform is absent): everything AROUND the transform
+    is the reference's, its fp32 summation order is the stand-in's ("parity unpinned" at that one boundary)."""
+    ck = np.load(os.path.join(HERE, ckpt_name))
+    frames = torch.from_numpy(np.load(os.path.join(HERE, "bunny8_640x1280.npz"))["frames"].copy()).float() / 255.0
+    n, B, iters = frames.shape[0], 2, 50
+    torch.manual_seed(1)
+    model = HNeRV(HNERV_3M) if arch == "hnerv" else NeRV(NERV_3M)
+    sd = {k[3:].replace("/", "."): torch.from_numpy(ck[k].astype(np.float32)) for k in ck.files if k.startswith("sd:")}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.startswith("encoder") for m in missing), (missing, unexpected)
+    model.eval()
+    emb = torch.from_numpy(ck["emb"].astype(np.float32))
+    out = {}
+    with torch.no_grad():
+        y_fp = torch.cat([model.decode(emb[i:i + 1])[0] for i in range(n)], 0)
+    out["psnr_fp"] = npy(psnr_frames(y_fp, frames))
+    print("  FP psnr", out["psnr_fp"].mean(), flush=True)
+    qnn = QuantModel(model=model, hadamard=True, weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
+    out["avgbits"] = np.array(qnn.set_bitwidth(BITS), dtype=np.float64)
+    qnn.eval()
+    qnn.set_quant_state(True)
+    with torch.no_grad():
+        qnn(emb[:B])
+        y_q0 = torch.cat([qnn(emb[i:i + 1])[0] for i in range(n)], 0)
+    out["psnr_q_noopt"] = npy(psnr_frames(y_q0, frames))
+    print("  quant w/o opt psnr", out["psnr_q_noopt"].mean(), flush=True)
+    qms = [m for m in qnn.model.modules() if isinstance(m, QuantModule)]
+    for li, m in enumerate(qms):
+        out[f"init_wdelta{li}"] = npy(m.weight_quantizer.delta)
+        out[f"init_wzp{li}"] = npy(m.weight_quantizer.zero_point)
+        out[f"init_bdelta{li}"] = npy(m.bias_quantizer.delta)
+        out[f"cpad{li}"] = np.array(m.hadamard_weight.shape[1])
+    g = torch.Generator().manual_seed(903)
+    n_ep = iters // (n // B)
+    order = torch.stack([torch.randperm(n, generator=g)[: (n // B) * B].view(n // B, B) for _ in range(n_ep)]).numpy()
+    out["order"] = order
+    loader = ReplayLoader(frames, order, n)
+    log = []
+    orig_call = ref_calib.LossFunction.__call__
+
+    def recording_call(self, pred, tgt, grad=None):
+        total = orig_call(self, pred, tgt, grad)
+        b = self.temp_decay(self.count)
+        if self.count < self.loss_start or self.round == "none":
+            b = 0
+        log.append((float(total), float(self.round_loss), float(b), self.count))
+        return total
+
+    ref_calib.LossFunction.__call__ = recording_call
+    t0 = time.time()
+    try:
+        ref_calib.model_reconstruction(qnn, cali_data=emb, gt=loader, arch=arch, batch_size=B, iters=iters, weight=0.01,
+                                       opt_mode="mse", hadamard=True, b_range=(20, 2), warmup=0.2, p=2.0, lr=0.003)
+    finally:
+        ref_calib.LossFunction.__call__ = orig_call
+    print(f"  model_reconstruction: {len(log)} iterations in {time.time() - t0:.1f}s", flush=True)
+    out["loss_log"] = np.array(log, dtype=np.float64)
+    out["iters"] = np.array(iters)
+    out["seconds_cpu8"] = np.array(time.time() - t0)
+    for li, m in enumerate(qms):   # final hard decisions, bit-packed (alpha >= 0 on all C_pad coefficients), and final scales
+        out[f"mask{li}"] = np.packbits((m.weight_quantizer.alpha.detach() >= 0).numpy().reshape(-1))
+        out[f"final_wdelta{li}"] = npy(m.weight_quantizer.delta)
+    qnn.set_quant_state(True)
+    with torch.no_grad():
+        y_q1 = torch.cat([qnn(emb[i:i + 1])[0] for i in range(n)], 0)
+    out["psnr_q_opt"] = npy(psnr_frames(y_q1, frames))
+    print("  quant w/ opt psnr", out["psnr_q_opt"].mean(), flush=True)
+    save(name, **out)
+
+
 GENS = {
     "uaq": gen_uaq,
     "adaround": gen_adaround,
@@ -681,6 +768,8 @@ GENS = {
     "traj_nerv_had": lambda: gen_traj("traj_nerv_had.npz", "nerv", NeRV, TINY_NERV, True, 200, 150, 2e-3, 904),
     "omega": gen_omega,
     "config1": gen_config1,
+    "config2": lambda: gen_fullsize_hadamard("config2_nerv3m_hadamard.npz", "nerv", "nerv3m_bunny8real_f16.npz"),
+    "config1_hadamard": lambda: gen_fullsize_hadamard("config1_hnerv3m_hadamard.npz", "hnerv", "hnerv3m_bunny8real_f16.npz"),
 }
 
 if __name__ == "__main__":

@@ -22,6 +22,13 @@ def test_header_symbols_exported():
     assert declared == set(_lib.EXPORTS)
     assert lib.nq_abi_version() == 3 == _lib.ABI_VERSION
     assert lib.nq_error_string(-1) == b"invalid argument"
+    # ... and nothing else: the library is built with -fvisibility=hidden, only NQ_API declarations are dynamic symbols
+    import shutil
+    import subprocess
+    nm = shutil.which("nm") or "/opt/rocm/lib/llvm/bin/llvm-nm"
+    out = subprocess.run([nm, "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if len(ln.split()) >= 3 and ln.split()[-2] in ("T", "t")}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():

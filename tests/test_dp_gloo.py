@@ -81,6 +81,45 @@ def _worker(rank, world, port, out):
             fin()
         assert torch.equal(arena, torch.arange(10, dtype=torch.float32) * 1.5), arena
         assert "gloo" in cm._AVG_OK      # decided (this gloo may or may not reduce with AVG; the mean is the same)
+        # the SUM-and-scale branch (a backend without ReduceOp.AVG), forced: same mean, in place, asynchronous
+        cm._AVG_OK["gloo"] = False
+        arena = torch.arange(10, dtype=torch.float32) * (rank + 1)
+        fins = [cm._mean_all_reduce(arena[:6]), cm._mean_all_reduce(arena[6:])]
+        for fin in fins:
+            fin()
+        assert torch.equal(arena, torch.arange(10, dtype=torch.float32) * 1.5), arena
+        # a backend that REFUSES AVG at the call: remembered, and the same call falls through to SUM-and-scale ...
+        real_all_reduce, calls = dist.all_reduce, []
+
+        def refusing(t, op=dist.ReduceOp.SUM, **kw):
+            calls.append(op)
+            if op == dist.ReduceOp.AVG:
+                raise RuntimeError("Cannot use ReduceOp.AVG with Gloo")
+            return real_all_reduce(t, op=op, **kw)
+
+        cm._AVG_OK.pop("gloo")
+        dist.all_reduce = refusing
+        try:
+            arena = torch.full((4,), float(rank + 1))
+            cm._mean_all_reduce(arena)()
+            assert torch.equal(arena, torch.full((4,), 1.5)) and cm._AVG_OK["gloo"] is False
+            assert calls == [dist.ReduceOp.AVG, dist.ReduceOp.SUM]
+            cm._mean_all_reduce(arena)()
+            assert calls[2:] == [dist.ReduceOp.SUM]          # decided once per backend
+            # ... but any OTHER error of the collective (a communicator fault) is not swallowed
+            cm._AVG_OK.pop("gloo")
+
+            def broken(t, op=dist.ReduceOp.SUM, **kw):
+                raise RuntimeError("NCCL communicator was aborted on rank 0")
+
+            dist.all_reduce = broken
+            try:
+                cm._mean_all_reduce(arena)
+                raise AssertionError("a communicator error must propagate")
+            except RuntimeError as e:
+                assert "aborted" in str(e) and "gloo" not in cm._AVG_OK
+        finally:
+            dist.all_reduce = real_all_reduce
         # bit-allocation sweep: candidates are dealt round-robin to the ranks, scores gathered everywhere
         from neuroquant_amd.methods import bit_assign as ba
         cands = {f"candidate{i + 1}": [2 + (i + j) % 6 for j in range(7)] for i in range(5)}

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import T, BITS, TINY_HNERV, state_dict_from_npz
+from conftest import ROOT, T, BITS, TINY_HNERV, state_dict_from_npz
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -438,3 +438,50 @@ def test_two_processes_gloo_on_gpu(golden, tmp_path, monkeypatch):
             assert np.abs(r0[f"delta_{tag}{i}"] - d).max() <= 1e-3 * np.abs(d).max()
             if a.size >= 1000:   # alpha moves by lr per step: a few elements flip sign of a near-zero gradient
                 assert (np.abs(r0[f"alpha_{tag}{i}"] - a) > 0.05).mean() < 0.01
+
+
+@pytest.mark.parametrize("extra,want_gb,want_scaling", [((), 4, "weak"), (("--global-batch", "16"), 16, "strong")])
+def test_bench_command_at_world_two(extra, want_gb, want_scaling):
+    """Rehearsal of the driver's SCALE command before hardware sees it: `bench.py --gpus 2 --steps 4 --warmup 2` as two fresh
+    processes under the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), both on this card, process group
+    gloo (NQ_DIST_BACKEND; RCCL refuses two ranks on one device).  Both ranks must exit 0, rank 0 alone prints ONE JSON line
+    with the data-parallel headline (n_gpus 2, dp2, the global batch, a roofline object) and the single-GPU secondary
+    objects suppressed."""
+    import json
+    import subprocess
+    import sys
+    port = _free_port()
+    bench = os.path.join(ROOT, "bench.py")
+    procs = []
+    for r in (0, 1):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NQ_DIST_BACKEND="gloo", RANK=str(r), LOCAL_RANK="0",
+                   WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.pop("NQ_DP_REHEARSAL", None)
+        procs.append(subprocess.Popen([sys.executable, bench, "--gpus", "2", "--steps", "4", "--warmup", "2", "--repeats", "1",
+                                       "--frames", "32", "--no-cpu-baseline", *extra], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE))
+    outs = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append((o.decode(errors="replace"), e.decode(errors="replace")))
+    assert all(p.returncode == 0 for p in procs), "\n".join(e[-3000:] for _, e in outs)
+    lines0 = [ln for ln in outs[0][0].splitlines() if ln.strip().startswith("{")]
+    lines1 = [ln for ln in outs[1][0].splitlines() if ln.strip().startswith("{")]
+    assert len(lines0) == 1 and not lines1, (outs[0][0][-500:], outs[1][0][-500:])
+    line = json.loads(lines0[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["warmup"] == 2
+    assert line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == want_gb
+    assert line["config"]["per_gpu_batch"] == want_gb // 2 and line["scaling"] == want_scaling
+    assert line["value"] > 0 and line["ms_per_step"] > 0 and line["higher_is_better"] is True
+    # weak: `value` counts B=2-equivalents of BOTH ranks; strong: global-batch iterations
+    units = 2 if want_scaling == "weak" else 1
+    assert abs(line["value"] - units * 1e3 / line["ms_per_step"]) <= 1e-2 * line["value"]
+    rl = line["roofline"]
+    assert rl and rl["frac"] > 0 and rl["kernel"].startswith("conv_") and f' B{want_gb // 2}' in rl["kernel"]
+    for k in ("fp32", "phase1", "nerv", "trained", "uvg", "psnr", "cpu_baseline"):
+        assert line[k] is None, k

@@ -268,7 +268,8 @@ def test_precision_gate_trained_hnerv_3m():
     o_it = int(os.environ.get("NQ_GATE_ORACLE_ITERS", "120"))
     args = types.SimpleNamespace(train_steps=int(os.environ.get("NQ_GATE_TRAIN_STEPS", "3000")), iters=2000,
                                  oracle_iters=o_it, frames="bunny", frames_n=8, cpu_threads=16, record=False, ckpt=None,
-                                 save_ckpt=None, seeds=[903, 904])
+                                 save_ckpt=None, seeds=[903])   # (one batch order x four arms: the full-length pair below
+                                                                # carries the precision claim now)
     res = pg.run(args)
     print({k: v for k, v in res.items() if k != "config"})
     assert res["fp_psnr"] >= 30.0, res["fp_psnr"]
@@ -279,8 +280,11 @@ def test_precision_gate_trained_hnerv_3m():
     # tests/golden/make_sensitivity.py; the full 21 000-iteration schedule collapses to < 0.01 dB and is held to 0.02 dB,
     # profiles/r02_precision_gate_21000.json): population means within S, single runs within 2 S, S = max(measured
     # self-spread, 0.08 dB) -- precision_gate.gate_ok
-    assert pg.gate_ok(res), {k: res[k] for k in ("q_opt_fp32_runs", "q_opt_bf16x3_runs", "fp32_self_spread_dB", "dmean_dB",
-                                                 "dpsnr_fp32_vs_bf16x3_dB", "welch_t")}
+    # Round 4: a SANITY bound only.  The precision claim (0.02 dB) is carried by the full-length pair below
+    # (test_full_length_calibration_fp32_vs_bf16x3), where the schedule has settled; a 2000-iteration run has not, and
+    # exact fp32 differs from itself by up to 0.09 dB here.
+    assert res["dpsnr_fp32_vs_bf16x3_dB"] <= 0.2 and res["dmean_dB"] <= 0.2, {
+        k: res[k] for k in ("q_opt_fp32_runs", "q_opt_bf16x3_runs", "fp32_self_spread_dB", "dmean_dB", "dpsnr_fp32_vs_bf16x3_dB")}
     o = res["oracle"]
     assert o["phase1_iterations"] >= 1 and o["iterations"] == o_it // 4 * 4
     # 120 iterations of a chaotic recursion on two machines with different summation orders (CPU oracle vs GPU): the final
@@ -296,3 +300,41 @@ def test_precision_gate_trained_hnerv_3m():
     # per-iteration parity evidence is the reference fixture above (48 logged iterations to 5e-5) and the single-step
     # gradient test, both deterministic.
     assert o["loss_rel_diff_fp32"]["max"] < 0.3 and o["loss_rel_diff_bf16x3"]["max"] < 0.3, o
+
+
+def test_full_length_calibration_fp32_vs_bf16x3(caplog):
+    """The long-run precision claim under the driver's eyes: ONE full-length calibration pair (iters_w = 21000 -> 1048
+    phase-1 + 19 952 phase-2 iterations on 8 frames; reference schedule calib_model.py:144, 205) with exact-fp32 and with
+    bf16x3 convolutions, batch-order seed 903, on the committed operating-point fixtures (hnerv3m_bunny8real_f16.npz: FP
+    38.07 dB on the eight real Bunny crops, bunny8_640x1280.npz).  North-star bar: |PSNR_bf16x3 - PSNR_fp32| <= 0.02 dB; both
+    must recover >= 1.5 dB over the un-optimised quantised model; the temperature the run logs at counts 4500 / 19500 is the
+    reference log's (b = 19.68 / 3.61, results/...052303.log:273, :303)."""
+    import logging
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import precision_gate as pg
+    n, B, iters = 8, 2, 21000
+    frames_u8 = pg.bunny_real_640(DEV, n)
+    model, emb, _ = pg.load_fixture_checkpoint("hnerv3m_bunny8real_f16.npz", DEV)
+    order = pg.make_order(n, B, iters, seed=903)
+    assert order.shape == (5250, 4, 2)
+    res = {}
+    with caplog.at_level(logging.INFO):
+        for prec in ("fp32", "bf16x3"):
+            caplog.clear()
+            r, _, _ = pg.calibrate_gpu(model, frames_u8, emb, order, iters, prec, record=False)
+            res[prec] = r
+            # the engine logs every 500th count of each phase like the reference (calib_model.py:86-88); phase 2 is the later one
+            b_at = {}
+            for rec in caplog.records:
+                m = re.search(r"b=([0-9.]+)\s+count=(\d+)", rec.getMessage())
+                if m:
+                    b_at[int(m.group(2))] = m.group(1)       # phase 2 overwrites phase 1's entries of the same count
+            assert b_at.get(4500) == "19.68" and b_at.get(19500) == "3.61", {k: b_at.get(k) for k in (500, 4500, 19500)}
+            print(f"[{prec}] 21k: {r['seconds']:.1f} s, PSNR w/o opt {r['q_noopt']:.4f} -> w/ opt {r['q_opt']:.4f} dB")
+    f32, b3 = res["fp32"], res["bf16x3"]
+    assert f32["q_noopt"] == b3["q_noopt"]                       # the same starting point (evaluated with exact fp32)
+    assert abs(b3["q_opt"] - f32["q_opt"]) <= 0.02, (f32["q_opt"], b3["q_opt"])
+    assert f32["q_opt"] >= f32["q_noopt"] + 1.5 and b3["q_opt"] >= b3["q_noopt"] + 1.5, (f32, b3)
+    # the default kernels evaluate the model they calibrated to the same number
+    assert abs(b3["q_opt_eval_bf16x3"] - b3["q_opt"]) <= 2e-3
