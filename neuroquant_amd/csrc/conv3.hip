@@ -1,6 +1,7 @@
 // C-ABI entry points of the bf16x3 convolution path (conv_igemm3_impl.h): weight pre-split/re-order + dispatch.
 #include <cstdlib>
 #include "nq_common.h"
+#include "conv3_layout.h"
 
 extern "C" {
 int nq_conv_igemm3_k3(const float*, const void*, const float*, float*, float*, const float*, int, int, int, int, int, int, int,
@@ -14,6 +15,9 @@ int nq_conv3_nst8_k3();
 int nq_conv3_nst8_k5();
 int nq_conv3_nstk_k3(int);
 int nq_conv3_nstk_k5(int);
+int nq_conv_flat3_plan(int, int, int, int, int, int, int*, int*, int*, int*);
+int nq_conv_flat3(const float*, const void*, const float*, float*, float*, const float*, float*, int, int, int, int, int, int, int, int,
+                  int, int, int, int, hipStream_t);
 int nq_conv_wgrad3_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int nq_conv_wgrad3_k5(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 }
@@ -64,33 +68,7 @@ struct WL3 {
   int co16;        // 16-channel groups of output channels: ceil(co_tiles*MT / 16)
   int64_t slots;
 };
-// k-value e (0..7) of lane group kq at k-step s of a chunk -> (channel within the chunk, tap); tap >= KK: zero weight.
-// (mirrors the B-fragment assembly of conv_igemm3_kernel, Conv3Args::tail)
-//   0 full chunk : 2 octets x 2 taps per step          ch = (kq&1)*8 + e, tap = 2s + (kq>>1)
-//   2 <= 8 ch    : 1 octet x 4 taps per step           ch = e,            tap = 4s + kq
-//   1 <= 4 ch    : slot j = 4s + kq = 4 channels x taps (2j, 2j+1)        ch = e & 3, tap = 2j + (e >> 2)
-//   3 <= 12 ch   : slots j < KK: octet 0 at tap j; slots KK + h: channels 8..11 x taps (2h, 2h+1)
-__device__ __forceinline__ void wl3_elem(int kind, int KK, int s, int kq, int e, int& ch, int& tap) {
-  const int j = 4 * s + kq;
-  if (kind == 2) {
-    ch = e;
-    tap = j;
-  } else if (kind == 1) {
-    ch = e & 3;
-    tap = 2 * j + (e >> 2);
-  } else if (kind == 3) {
-    if (j < KK) {
-      ch = e;
-      tap = j;
-    } else {
-      ch = 8 + (e & 3);
-      tap = 2 * (j - KK) + (e >> 2);
-    }
-  } else {
-    ch = (kq & 1) * 8 + e;
-    tap = 2 * s + (kq >> 1);
-  }
-}
+// (k-value e of lane group kq at k-step s -> (channel, tap): wl3_elem, conv3_layout.h)
 
 // One workgroup per (16-channel chunk c of the logical input channels, group of 16 logical output channels): the 16 x 16 x KK
 // weights it needs are 16 CONTIGUOUS runs of 16*KK floats in the stored tensor (rows = co for the forward operand, = ch
@@ -186,7 +164,10 @@ inline Fwd3Plan plan_fwd3(int B, int Cin, int H, int W, int Cout) {
   const int nchunk = (Cin + CC - 1) / CC;
   p.nsplit = 1;
   p.per = nchunk;
-  if (p.wgs < 256) {
+  // (a K loop of <= 4 chunks is not worth splitting: the slabs and the finish launch cost more than the half-empty round --
+  // NeRV's 36 -> 384 layer at 40 x 80: 180 workgroups, 20.0 + 23.2 us split in two vs one launch without slabs)
+  static const int min_chunks = [] { const char* e = getenv("NQ_SPLITK_MIN_CHUNKS"); return e ? atoi(e) : 5; }();
+  if (p.wgs < 256 && nchunk >= min_chunks) {
     int want = (int)(512 / p.wgs);   // floor: stay within ONE round of 512 resident workgroups (a second, nearly empty
                                      // round costs as much as the first)
     if (want > nchunk) want = nchunk;
@@ -194,6 +175,19 @@ inline Fwd3Plan plan_fwd3(int B, int Cin, int H, int W, int Cout) {
     p.nsplit = (nchunk + p.per - 1) / p.per;
   }
   return p;
+}
+
+// Few-pixel layers (conv_flat3.hip): taken when the flat kernel needs no slabs (forward convolutions of the deep layers: no
+// finish launch), or when the tiled kernel's grid would not fill the chip even with split-K (it would fall back to the fp32
+// kernels).  Long K loops that the tiled split-K path already handles stay there: measured (us, kernel + finish) HNeRV dec2
+// data gradient 21.0 flat vs 21.7 tiled, NeRV dec1 data gradient 22.4 vs 18.7, NeRV dec2 data gradient 19.3 vs 25.6 (fp32).
+inline bool use_flat3(int B, int Cin, int H, int W, int Cout, int k, int* fns) {
+  int ns = 1;
+  if (!nq_conv_flat3_plan(B, Cin, H, W, Cout, k, nullptr, nullptr, &ns, nullptr)) return false;
+  if (fns) *fns = ns;
+  if (ns == 1) return true;
+  const Fwd3Plan p = plan_fwd3(B, Cin, H, W, Cout);
+  return p.wgs * p.nsplit < 128;
 }
 
 struct Wg3Plan {
@@ -396,12 +390,15 @@ int nq_conv3_supported(int B, int Cin, int H, int W, int Cout, int k) {
   // the kernel addresses the input with 32-bit buffer offsets (conv_igemm3_impl.h): tensors of 4 GiB and more stay on
   // the fp32 kernels
   if ((int64_t)B * Cin * H * W * 4 >= 0xFFFFFF00ll) return 0;
+  if (use_flat3(B, Cin, H, W, Cout, k, nullptr)) return 1;   // few-pixel kernel (conv_flat3.hip)
   const Fwd3Plan p = plan_fwd3(B, Cin, H, W, Cout);
-  return p.wgs * p.nsplit >= 192;  // still smaller grids stay on the fp32 split-K kernel
+  return p.wgs * p.nsplit >= 128;  // still smaller grids stay on the fp32 split-K kernel
 }
 
 int64_t nq_conv_forward3_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
   if (!(k == 3 || k == 5) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  int fns = 1;
+  if (use_flat3(B, Cin, H, W, Cout, k, &fns)) return fns > 1 ? (int64_t)fns * B * Cout * H * W : 0;
   const Fwd3Plan p = plan_fwd3(B, Cin, H, W, Cout);
   return p.nsplit > 1 ? (int64_t)p.nsplit * B * Cout * H * W : 0;
 }
@@ -460,9 +457,20 @@ int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* 
   if ((epilogue == NQ_EPI_PS_GELU || epilogue == NQ_EPI_PS) && (!z || r <= 0 || Cout % (r * r) != 0)) return NQ_ERR_INVALID;
   if (epilogue == NQ_EPI_DGRAD_GELU && (!zprev || r <= 0 || H % r != 0 || W % r != 0)) return NQ_ERR_INVALID;
   if (B > 65535) return NQ_ERR_UNSUPPORTED;
+  hipStream_t st = nq_s(stream);
+  {   // few-pixel layers: pixels of all frames as one flat GEMM dimension, waves split the K loop (conv_flat3.hip)
+    int fns = 1;
+    if (use_flat3(B, Cin, H, W, Cout, k, &fns)) {
+      if (fns > 1 && !ws) return NQ_ERR_INVALID;
+      const int mi = pick_mi3(Cout), kind = tail_kind_of(Cin, mi);
+      int rc = nq_conv_flat3(x, wt3, bias, y, z, zprev, ws, B, Cin, H, W, Cout, k, r, epilogue, 16 * mi, kind, nst_of(k),
+                             nstk_of(k, kind), st);
+      if (rc != NQ_OK || fns == 1) return rc;
+      return nq_conv_splitk_finish(ws, bias, y, z, zprev, B, H, W, Cout, r, epilogue, fns, st);
+    }
+  }
   const Fwd3Plan p = plan_fwd3(B, Cin, H, W, Cout);
   if (p.nsplit > 1 && !ws) return NQ_ERR_INVALID;
-  hipStream_t st = nq_s(stream);
   int rc = (k == 3) ? nq_conv_igemm3_k3(x, wt3, bias, y, z, zprev, B, Cin, H, W, Cout, r, epilogue, p.mi, p.nsplit, p.per, ws, st)
                     : nq_conv_igemm3_k5(x, wt3, bias, y, z, zprev, B, Cin, H, W, Cout, r, epilogue, p.mi, p.nsplit, p.per, ws, st);
   if (rc != NQ_OK || p.nsplit == 1) return rc;

@@ -254,6 +254,90 @@ def test_config1_reference_fixture(golden, prec):
         ops.set_conv_precision(None)
 
 
+@pytest.mark.parametrize("prec", ("fp32", "bf16x3"))
+@pytest.mark.parametrize("fixture,arch,ckpt", [("config2_nerv3m_hadamard.npz", "nerv", "nerv3m_bunny8real_f16.npz"),
+                                               ("config1_hnerv3m_hadamard.npz", "hnerv", "hnerv3m_bunny8real_f16.npz")])
+def test_hadamard_reference_fixture(golden, fixture, arch, ckpt, prec):
+    """The Hadamard path at FULL size against the REAL reference (round 4; tests/golden/make_golden.py::gen_fullsize_hadamard ran
+    /root/reference's own QuantModel(hadamard=True) + model_reconstruction): BASELINE configs[2] = NeRV Bunny_1280x640_3M with
+    --hadamard (C_in padded to 256 / 256 / 128 / 64 / 32 / 32 / 32) and HNeRV-3M with --hadamard (16 / 128 / 128 / 64 / 64 / 64 /
+    64), trained checkpoints, the eight real 640x1280 Bunny crops, bits 6 5 4 5 5 6 6, B = 2, iters_w = 50 -> 48 phase-2
+    iterations in the recorded order.  Checked: the initial scales and zero points on the PADDED TRANSFORM-DOMAIN weights
+    bit-exact (quant_layer.py:44-49), the average bit-width, PSNR FP / w/o opt / w/ opt to 2e-3 dB, every one of the 48
+    (total, round, b, count) log entries to 5e-5 -- the regulariser runs over all C_pad coefficients (calib_model.py:170-191)
+    -- and the final hard-rounding decisions.  (The butterflies of the fixture are the stand-in's: parity at the transform's own
+    fp32 summation order stays unpinned, tests/golden/_ref_stubs.py.)"""
+    import tools_path  # noqa: F401
+    import precision_gate as pg
+    from neuroquant_amd import ops
+    from neuroquant_amd.models import HNeRV, NeRV
+    from neuroquant_amd.quantization import QuantModel, model_reconstruction
+    from neuroquant_amd.utils import CacheLoader, FrameCache
+    import bench
+    z, ck = golden(fixture), golden(ckpt)
+    frames_u8 = pg.bunny_real_640(DEV, 8)
+    frames = frames_u8.float() / 255.0
+    torch.manual_seed(1)
+    model = HNeRV(bench.HNERV_3M) if arch == "hnerv" else NeRV(bench.NERV_3M)
+    sd = {k[3:].replace("/", "."): torch.from_numpy(v.astype(np.float32)) for k, v in ck.items() if k.startswith("sd:")}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.startswith("encoder") for m in missing)
+    model = model.to(DEV).eval()
+    emb = torch.from_numpy(ck["emb"].astype(np.float32)).to(DEV)
+    ops.set_conv_precision(prec)
+    try:
+        qnn = QuantModel(model, hadamard=True, weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
+        assert qnn.set_bitwidth(BITS) == float(z["avgbits"])
+        if arch == "nerv":
+            assert float(z["avgbits"]) == 4.946213722986429              # reference log ...080342.log:143
+        qnn.eval()
+
+        def psnr():
+            with torch.no_grad():
+                return torch.cat([ops.frame_psnr(qnn(emb[i:i + 1])[0], frames[i:i + 1]) for i in range(8)]).cpu().numpy()
+
+        qnn.set_quant_state(False)
+        np.testing.assert_allclose(psnr(), z["psnr_fp"], atol=2e-3)
+        qnn.set_quant_state(True)
+        with torch.no_grad():
+            qnn(emb[:2])
+        mods = qnn.quant_modules()
+        for li, m in enumerate(mods):
+            assert m.hadamard_weight.shape[1] == int(z[f"cpad{li}"])                                       # padded length
+            assert np.array_equal(m.weight_quantizer.delta.detach().cpu().numpy(), z[f"init_wdelta{li}"]), li   # bit-exact
+            assert np.array_equal(m.weight_quantizer.zero_point.detach().cpu().numpy(), z[f"init_wzp{li}"]), li
+            assert np.array_equal(m.bias_quantizer.delta.detach().cpu().numpy(), z[f"init_bdelta{li}"]), li
+        np.testing.assert_allclose(psnr(), z["psnr_q_noopt"], atol=2e-3)
+        rec = []
+        loader = CacheLoader(FrameCache(frames_u8), list(range(8)), 2, order=z["order"])
+        model_reconstruction(qnn, cali_data=emb, gt=loader, arch=arch, batch_size=2, iters=int(z["iters"]), weight=0.01,
+                             hadamard=True, b_range=(20, 2), warmup=0.2, lr=0.003, recorder=rec)
+        log, ref = np.array(rec), z["loss_log"]
+        assert log.shape == ref.shape == (48, 4)
+        np.testing.assert_array_equal(log[:, 2:], ref[:, 2:])                 # temperature, counter
+        rel = np.abs(log[:, 0] - ref[:, 0]) / np.abs(ref[:, 0])
+        qnn.set_quant_state(True)
+        got = psnr()
+        print(f"{fixture} vs reference [{prec}]: loss rel diff max {rel.max():.2e}; PSNR w/ opt {got.mean():.4f} vs {z['psnr_q_opt'].mean():.4f}")
+        np.testing.assert_allclose(log[:, 0], ref[:, 0], rtol=5e-5)
+        np.testing.assert_allclose(log[:, 1], ref[:, 1], rtol=5e-5, atol=1e-6)
+        np.testing.assert_allclose(got, z["psnr_q_opt"], atol=5e-3)
+        assert abs(float(got.mean()) - float(z["psnr_q_opt"].mean())) < 2e-3     # north-star bar is 0.02 dB
+        # final hard decisions on all C_pad coefficients: alpha moved by <= 48 * lr from where h(alpha) = frac(w / delta), so only
+        # coefficients that start within that distance of the threshold can end on the other side of it
+        same = tot = 0
+        for li, m in enumerate(mods):
+            mask = (m.weight_quantizer.alpha.detach() >= 0).cpu().numpy().reshape(-1)
+            want = np.unpackbits(z[f"mask{li}"])[: mask.size].astype(bool)
+            same += int((mask == want).sum())
+            tot += mask.size
+            np.testing.assert_allclose(m.weight_quantizer.delta.detach().cpu().numpy(), z[f"final_wdelta{li}"], rtol=0, atol=0)
+        print(f"  hard-rounding masks equal to the reference: {same / tot:.6f}")
+        assert same / tot > 0.999, same / tot
+    finally:
+        ops.set_conv_precision(None)
+
+
 def test_precision_gate_trained_hnerv_3m():
     """tools/precision_gate.py at reduced length: HNeRV-3M fitted to >= 30 dB on the 8 Bunny-derived frames, then
     (a) 2000-iteration calibrations (100 phase-1 + 1900 phase-2 iterations) for two recorded batch orders under exact

@@ -264,7 +264,15 @@ def test_conv_forward_backward(ops, case):
                                   # K loops SHORTER than the LDS-DMA ring's prefetch distance (2 / 4 / 2 k-steps on the 48-, 80-
                                   # and 64-channel tiles), and a ring that wraps many times behind a split-K (deep, narrow input)
                                   (2, 3, 32, 64, 48, 3, "psgelu", 2), (2, 4, 32, 64, 80, 5, "plain", 1),
-                                  (2, 2, 40, 72, 64, 3, "tanh", 1), (1, 333, 8, 32, 48, 3, "plain", 1)])
+                                  (2, 2, 40, 72, 64, 3, "tanh", 1), (1, 333, 8, 32, 48, 3, "plain", 1),
+                                  # few-pixel layers (conv_flat3.hip: pixels of all frames as one flat GEMM dimension, waves split
+                                  # the K loop): HNeRV dec2 / NeRV dec1, dec2 and their data gradients, every tail kind, k = 5, a
+                                  # ragged last pixel block (B = 3), the workgroup-level split of a long K loop
+                                  (2, 77, 10, 20, 1024, 3, "psgelu", 4), (2, 1024, 10, 20, 77, 3, "dgrad", 5),
+                                  (2, 145, 2, 4, 1800, 3, "psgelu", 5), (2, 1800, 2, 4, 145, 3, "plain", 1),
+                                  (2, 72, 10, 20, 576, 3, "psgelu", 4), (2, 576, 10, 20, 72, 3, "dgrad", 5),
+                                  (3, 20, 5, 9, 40, 5, "plain", 1), (1, 9, 10, 20, 24, 5, "psgelu", 2), (2, 44, 6, 11, 35, 3, "tanh", 1),
+                                  (1, 2000, 2, 4, 30, 3, "plain", 1), (2, 12, 10, 20, 64, 3, "psgelu", 2)])
 def test_conv_bf16x3(ops, case):
     """bf16x3 kernel (split operands on the BF16 matrix pipe) vs float64: error stays at the fp32 level (a few 1e-6
     relative to the output scale), forward epilogues and the data-gradient operand (transposed=True) included.  Grids
@@ -316,6 +324,22 @@ def test_wgrad_bf16x3(ops, case):
     close(db, dy.double().sum((0, 2, 3)), rtol=2e-5, atol=1e-5 * float(dy.double().sum((0, 2, 3)).abs().max()) + 1e-4)
     dw2, db2 = ops.conv_wgrad3_raw(x.to(DEV), dy.to(DEV), Cout, k, True)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
+
+
+def test_few_pixel_layers_take_the_flat_kernel():
+    """The plan of conv_flat3.hip (pure host function behind nq_conv3_supported / nq_conv_forward3_ws_floats): the deep layers of
+    both 3M models are offered to it, the big ones are not, and only long K loops on small grids leave slabs."""
+    from neuroquant_amd import _lib
+    lib = _lib.lib()
+    for B, cin, H, W, cout, k, slabs in [(2, 77, 10, 20, 1024, 3, False), (2, 1024, 10, 20, 77, 3, None), (2, 145, 2, 4, 1800, 3, False),
+                                         (2, 1800, 2, 4, 145, 3, None), (2, 72, 10, 20, 576, 3, False), (2, 576, 10, 20, 72, 3, None)]:
+        assert lib.nq_conv3_supported(B, cin, H, W, cout, k) == 1
+        ws = lib.nq_conv_forward3_ws_floats(B, cin, H, W, cout, k)
+        if slabs is False:
+            assert ws == 0, (cin, cout, ws)       # forward of a deep layer: no slabs, no finish launch
+        else:
+            assert ws % (B * cout * H * W) == 0
+    assert lib.nq_conv_forward3_ws_floats(2, 44, 320, 640, 148, 5) == 0
 
 
 def test_wgrad_swapped_roles_small_cout(ops):

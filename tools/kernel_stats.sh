@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/kstats
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --frames 8 --no-cpu-baseline --no-fp32 --steps 40 --warmup 6 > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $R/bench.py --frames 8 --no-cpu-baseline --no-fp32 --no-trained --no-uvg --steps 40 --warmup 6 > $OUT/bench.log 2>&1
 cd $R
 python3 - "$@" <<'PY'
 import csv, glob, sys

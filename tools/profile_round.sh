@@ -9,7 +9,16 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --frames 8 --workload $WL --no-cpu-baseline --no-fp32 --no-nerv --no-phase1 --repeats 1"
+MODE=${3:-full}         # full | trace (only the per-iteration kernel sequence: one short run)
+BENCH="python3 $R/bench.py --frames 8 --workload $WL --no-cpu-baseline --no-fp32 --no-nerv --no-phase1 --no-trained --no-uvg --repeats 1"
+if [ "$MODE" = "trace" ]; then
+  rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- $BENCH --steps 12 --warmup 5 > $OUT/trace.log 2>&1
+  cd $R
+  python3 tools/trace_step.py $OUT/trace $OUT/${TAG}_step_sequence.txt
+  grep '^{' $OUT/trace.log | tail -1 | cut -c1-200
+  rm -rf $OUT/trace
+  exit 0
+fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH --steps 40 --warmup 6 > $OUT/stats.log 2>&1
 export NQ_GRAPH=0
 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/fetch -- $BENCH --steps 3 --warmup 1 > $OUT/fetch.log 2>&1
