@@ -333,6 +333,18 @@ NQ_API int nq_frame_sse(const float* out, const float* gt, float* sse, int64_t f
 NQ_API int nq_gather_frames_u8(const uint8_t* src, const int64_t* idx, float* dst, int64_t n, int64_t frame_len,
                         nq_stream_t stream);
 
+/* ---- twice-differentiable elementwise pieces of the decoder (ABI v4): the Omega bit-allocation criterion differentiates
+ * the decoder twice (Hessian-vector products by double backward, methods/bit_assign.py:57-118, 171-217), through
+ * PixelShuffle, the exact-erf GELU (models/_layers.py:20-36, 104-105) and OutImg's tanh (models/_layers.py:10-16).
+ *   nq_act_dd        y[i] = f(x[i]) * (g ? g[i] : 1) * (g2 ? g2[i] : 1);  mode 0 / 1 / 2: gelu, gelu', gelu''
+ *                    (gelu'' = phi(x) (2 - x^2));  mode 3 / 4 / 5: t = tanh(x): 0.5 t + 0.5, 0.5 (1 - t^2), -t (1 - t^2)
+ *   nq_pixel_shuffle inverse = 0: (B, C*r*r, H, W) -> (B, C, H*r, W*r) (torch.nn.PixelShuffle); inverse = 1: the un-shuffle
+ *   nq_bias_add      y[b][c][p] = (x ? x[b][c][p] : 0) + bias[c]  (the bias term of F.conv2d, quant_layer.py:80; x = NULL
+ *                    broadcasts the bias: the backward of a channel sum) */
+NQ_API int nq_act_dd(const float* x, const float* g, const float* g2, float* y, int64_t n, int mode, nq_stream_t stream);
+NQ_API int nq_pixel_shuffle(const float* x, float* y, int B, int C, int H, int W, int r, int inverse, nq_stream_t stream);
+NQ_API int nq_bias_add(const float* x, const float* bias, float* y, int B, int C, int64_t HW, nq_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NQ_LIB") or os.path.join(_HERE, "libnqhip.so")
 
 NQ_OK = 0
-ABI_VERSION = 3   # nq_abi_version() of the library this binding was written against (include/nq_hip.h)
+ABI_VERSION = 4   # nq_abi_version() of the library this binding was written against (include/nq_hip.h)
 EPI_PLAIN, EPI_PS_GELU, EPI_TANH, EPI_PS, EPI_DGRAD_GELU = 0, 1, 2, 3, 4
 
 
@@ -130,6 +130,9 @@ def _load():
     sig("nq_l2_loss_tanh_head", I, P, P, P, P, P, P, P, P, I, I, L, L, F, P)
     sig("nq_frame_sse", I, P, P, P, L, L, P)
     sig("nq_gather_frames_u8", I, P, P, P, L, L, P)
+    sig("nq_act_dd", I, P, P, P, P, L, I, P)
+    sig("nq_pixel_shuffle", I, P, P, I, I, I, I, I, I, P)
+    sig("nq_bias_add", I, P, P, P, I, I, L, P)
     return lib
 
 
@@ -142,6 +145,7 @@ EXPORTS = (
     "nq_conv_wgrad3_slabs", "nq_conv_wgrad3_swapped_slabs", "nq_conv_wgrad_slabs", "nq_wgrad_reduce_multi",
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",
     "nq_channel_sum", "nq_l2_loss_tanh_head", "nq_frame_sse", "nq_gather_frames_u8",
+    "nq_act_dd", "nq_pixel_shuffle", "nq_bias_add",
 )
 
 _lib = None

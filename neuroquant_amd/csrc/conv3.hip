@@ -390,7 +390,9 @@ int nq_conv3_supported(int B, int Cin, int H, int W, int Cout, int k) {
   // the kernel addresses the input with 32-bit buffer offsets (conv_igemm3_impl.h): tensors of 4 GiB and more stay on
   // the fp32 kernels
   if ((int64_t)B * Cin * H * W * 4 >= 0xFFFFFF00ll) return 0;
-  if (use_flat3(B, Cin, H, W, Cout, k, nullptr)) return 1;   // few-pixel kernel (conv_flat3.hip)
+  // few-pixel kernel (conv_flat3.hip) -- offered for layers whose weight tensor is worth streaming; a toy convolution (a few
+  // hundred weights) stays on the exact-fp32 kernels: nothing to gain, and its callers keep fp32-level results
+  if (use_flat3(B, Cin, H, W, Cout, k, nullptr) && (int64_t)Cin * k * k * Cout >= 65536) return 1;
   const Fwd3Plan p = plan_fwd3(B, Cin, H, W, Cout);
   return p.wgs * p.nsplit >= 128;  // still smaller grids stay on the fp32 split-K kernel
 }

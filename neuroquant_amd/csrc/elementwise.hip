@@ -182,9 +182,84 @@ __global__ __launch_bounds__(TPB) void gather_u8_kernel(const uint8_t* __restric
   }
 }
 
+// ---- twice-differentiable elementwise pieces of the decoder (Omega bit-allocation criterion: Hessian-vector products by
+//      double backward, reference methods/bit_assign.py:57-118 through models/_layers.py:10-36, 104-105) ----
+// y = f(x) * g * g2 (g, g2 optional), f = the value / first / second derivative of the exact-erf GELU (nn.GELU()) or of
+// OutImg's tanh(x) * 0.5 + 0.5.  erff / expf / tanhf: this is the bit-allocation sweep, not the calibration iteration.
+__device__ __forceinline__ float act_dd_eval(float x, int mode) {
+  const float kInvSqrt2 = 0.70710678118654752440f, kInvSqrt2Pi = 0.39894228040143267794f;
+  if (mode <= 2) {
+    const float cdf = 0.5f * (1.0f + erff(x * kInvSqrt2));
+    if (mode == 0) return x * cdf;
+    const float pdf = kInvSqrt2Pi * expf(-0.5f * x * x);
+    if (mode == 1) return cdf + x * pdf;
+    return pdf * (2.0f - x * x);          // gelu'' = 2 phi + x phi' = phi (2 - x^2)
+  }
+  const float t = tanhf(x);
+  if (mode == 3) return t * 0.5f + 0.5f;
+  const float s = 1.0f - t * t;
+  if (mode == 4) return 0.5f * s;
+  return -t * s;                          // (0.5 (1 - t^2))' = -t (1 - t^2)
+}
+__global__ __launch_bounds__(TPB) void act_dd_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                     const float* __restrict__ g2, float* __restrict__ y, int64_t n, int mode) {
+  const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (i >= n) return;
+  float v = act_dd_eval(x[i], mode);
+  if (g) v *= g[i];
+  if (g2) v *= g2[i];
+  y[i] = v;
+}
+// PixelShuffle(r): (B, C*r*r, H, W) -> (B, C, H*r, W*r), out[b][c][y*r+i][x*r+j] = in[b][c*r*r + i*r + j][y][x]; inverse = the
+// un-shuffle.  One thread per element of the SHUFFLED tensor (its side is contiguous across lanes).
+__global__ __launch_bounds__(TPB) void pixel_shuffle_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int H,
+                                                            int W, int r, int inverse, int64_t n) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= n) return;
+  const int Wr = W * r, Hr = H * r;
+  const int X = (int)(e % Wr);
+  const int64_t t = e / Wr;
+  const int Y = (int)(t % Hr);
+  const int64_t bc = t / Hr;                       // b*C + c
+  const int yy = Y / r, i = Y - yy * r, xx = X / r, j = X - xx * r;
+  const int64_t u = ((bc * (r * r) + i * r + j) * H + yy) * (int64_t)W + xx;   // index in the un-shuffled tensor
+  if (inverse) out[u] = in[e];
+  else out[e] = in[u];
+}
+// y[b][c][p] = (x ? x[b][c][p] : 0) + bias[c]
+__global__ __launch_bounds__(TPB) void bias_add_kernel(const float* __restrict__ x, const float* __restrict__ bias,
+                                                       float* __restrict__ y, int C, int64_t HW, int64_t n) {
+  const int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x;
+  if (e >= n) return;
+  const int c = (int)((e / HW) % C);
+  y[e] = (x ? x[e] : 0.f) + bias[c];
+}
+
 }  // namespace
 
 extern "C" {
+
+int nq_act_dd(const float* x, const float* g, const float* g2, float* y, int64_t n, int mode, nq_stream_t stream) {
+  if (!x || !y || n <= 0 || mode < 0 || mode > 5) return NQ_ERR_INVALID;
+  hipLaunchKernelGGL(act_dd_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, nq_s(stream), x, g, g2, y, n, mode);
+  return nq_launch_status();
+}
+
+int nq_pixel_shuffle(const float* x, float* y, int B, int C, int H, int W, int r, int inverse, nq_stream_t stream) {
+  if (!x || !y || x == y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || r <= 0) return NQ_ERR_INVALID;
+  const int64_t n = (int64_t)B * C * r * r * H * W;
+  hipLaunchKernelGGL(pixel_shuffle_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, nq_s(stream), x, y, C, H, W, r,
+                     inverse ? 1 : 0, n);
+  return nq_launch_status();
+}
+
+int nq_bias_add(const float* x, const float* bias, float* y, int B, int C, int64_t HW, nq_stream_t stream) {
+  if (!bias || !y || B <= 0 || C <= 0 || HW <= 0) return NQ_ERR_INVALID;
+  const int64_t n = (int64_t)B * C * HW;
+  hipLaunchKernelGGL(bias_add_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, nq_s(stream), x, bias, y, C, HW, n);
+  return nq_launch_status();
+}
+
 
 int nq_ps_gelu_backward(const float* da, const float* z, float* dconv, int B, int C, int H, int W, int r,
                         nq_stream_t stream) {

@@ -806,26 +806,175 @@ class _ConvWg(Function):
                 _ConvF.apply(x, G) if ctx.needs_input_grad[1] else None, None)
 
 
+# ---- the elementwise pieces of the decoder, twice differentiable on this repo's own kernels (round 4: they went through
+#      ATen before).  Each Function's backward is built from Functions of the same family, so
+#      torch.autograd.grad(create_graph=True) followed by .backward() -- the reference's Hessian-vector recipe,
+#      methods/bit_assign.py:88-114 -- never leaves libnqhip. ----
+_ACT_BASE = {"gelu": 0, "tanh": 3}
+
+
+def act_dd_raw(x, kind, order, g=None, g2=None):
+    """f^(order)(x) * g * g2 (nq_act_dd): kind 'gelu' = exact-erf GELU (nn.GELU(), _layers.py:104-105), 'tanh' = OutImg's
+    tanh(x)*0.5+0.5 (_layers.py:10-16); order 0 / 1 / 2 = value, first and second derivative."""
+    x = _dev(x, "x")
+    g = _dev(g, "g") if g is not None else None
+    g2 = _dev(g2, "g2") if g2 is not None else None
+    y = torch.empty_like(x)
+    L.check(L.lib().nq_act_dd(_p(x), _p(g), _p(g2), _p(y), x.numel(), _ACT_BASE[kind] + order, _stream()), "act_dd")
+    return y
+
+
+class _ActDD(Function):
+    """y = f^(order)(x) * g  (g may be None).  d/dx = gy * g * f^(order+1)(x), d/dg = gy * f^(order)(x): the same Function one
+    order up / without g, so the graph of a backward pass is itself differentiable (up to the second derivative: the
+    Hessian-vector products need no more; a third is refused loudly)."""
+
+    @staticmethod
+    def forward(ctx, x, g, kind, order):
+        ctx.save_for_backward(x, g)
+        ctx.kind, ctx.order = kind, order
+        return act_dd_raw(x, kind, order, g)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, g = ctx.saved_tensors
+        gy = gy.contiguous()
+        dx = dg = None
+        if ctx.needs_input_grad[0]:
+            if ctx.order >= 2:
+                raise NotImplementedError("third derivative of the activation is not built (Hessian-vector products need two)")
+            dx = _ActDD2.apply(x, gy, g, ctx.kind, ctx.order + 1)
+        if g is not None and ctx.needs_input_grad[1]:
+            dg = _ActDD.apply(x, gy, ctx.kind, ctx.order)
+        return dx, dg, None, None
+
+
+class _ActDD2(Function):
+    """y = f^(order)(x) * g * h (h may be None): the d/dx of _ActDD with its two multipliers kept apart (no elementwise product
+    outside the kernel).  Differentiable w.r.t. g and h (what the second backward pass asks for) and, while order < 2, x."""
+
+    @staticmethod
+    def forward(ctx, x, g, h, kind, order):
+        ctx.save_for_backward(x, g, h)
+        ctx.kind, ctx.order = kind, order
+        return act_dd_raw(x, kind, order, g, h)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, g, h = ctx.saved_tensors
+        gy = gy.contiguous()
+        dx = dg = dh = None
+        if ctx.needs_input_grad[0]:
+            if ctx.order >= 2 or h is not None:
+                raise NotImplementedError("third derivative of the activation is not built (Hessian-vector products need two)")
+            dx = _ActDD2.apply(x, gy, g, ctx.kind, ctx.order + 1)
+        if ctx.needs_input_grad[1]:
+            dg = _ActDD2.apply(x, gy, h, ctx.kind, ctx.order) if h is not None else _ActDD.apply(x, gy, ctx.kind, ctx.order)
+        if h is not None and ctx.needs_input_grad[2]:
+            dh = _ActDD2.apply(x, gy, g, ctx.kind, ctx.order)
+        return dx, dg, dh, None, None
+
+
+def gelu_dd(x):
+    """exact-erf GELU, twice differentiable (reference nn.GELU(), models/_layers.py:104-105)."""
+    return _ActDD.apply(x.contiguous(), None, "gelu", 0)
+
+
+def tanh_out_dd(x):
+    """OutImg: tanh(x) * 0.5 + 0.5, twice differentiable (reference models/_layers.py:10-16)."""
+    return _ActDD.apply(x.contiguous(), None, "tanh", 0)
+
+
+def pixel_shuffle_raw(x, r, inverse=False):
+    x = _dev(x, "x")
+    B, Cx, Hx, Wx = x.shape
+    if inverse:
+        if Hx % r or Wx % r:
+            raise ValueError("pixel_unshuffle: spatial size not divisible by r")
+        C, H, W = Cx, Hx // r, Wx // r
+        y = torch.empty((B, C * r * r, H, W), device=x.device, dtype=torch.float32)
+    else:
+        if Cx % (r * r):
+            raise ValueError("pixel_shuffle: channels not divisible by r*r")
+        C, H, W = Cx // (r * r), Hx, Wx
+        y = torch.empty((B, C, H * r, W * r), device=x.device, dtype=torch.float32)
+    L.check(L.lib().nq_pixel_shuffle(_p(x), _p(y), B, C, H, W, r, 1 if inverse else 0, _stream()), "pixel_shuffle")
+    return y
+
+
+class _PixelShuffleDD(Function):
+    """PixelShuffle(r) / its inverse: a permutation, so the backward is the inverse permutation of the same family (any order)."""
+
+    @staticmethod
+    def forward(ctx, x, r, inverse):
+        ctx.r, ctx.inverse = r, inverse
+        return pixel_shuffle_raw(x.contiguous(), r, inverse)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return _PixelShuffleDD.apply(gy.contiguous(), ctx.r, not ctx.inverse), None, None
+
+
+def pixel_shuffle_dd(x, r):
+    """torch.nn.PixelShuffle(r) (reference models/_layers.py:20-36), differentiable to any order."""
+    return _PixelShuffleDD.apply(x, r, False)
+
+
+class _BiasAddDD(Function):
+    """y = x + bias[None, :, None, None].  d/dx = gy, d/dbias = channel sums of gy -- a Function whose backward is the
+    broadcast again: linear, differentiable to any order."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        x, bias = _dev(x, "x").contiguous(), _dev(bias, "bias").contiguous()
+        y = torch.empty_like(x)
+        B, C = x.shape[0], x.shape[1]
+        L.check(L.lib().nq_bias_add(_p(x), _p(bias), _p(y), B, C, x.numel() // (B * C), _stream()), "bias_add")
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        gy = gy.contiguous()
+        return (gy if ctx.needs_input_grad[0] else None), (_ChannelSumDD.apply(gy) if ctx.needs_input_grad[1] else None)
+
+
+class _ChannelSumDD(Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return channel_sum(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):   # broadcast of g over (B, :, H, W)
+        g = _dev(g, "g").contiguous()
+        B, C = ctx.shape[0], ctx.shape[1]
+        y = torch.empty(ctx.shape, device=g.device, dtype=torch.float32)
+        L.check(L.lib().nq_bias_add(None, _p(g), _p(y), B, C, y.numel() // (B * C), _stream()), "bias_add")
+        return y
+
+
 def conv2d_dd(x, w, b=None):
     """stride-1 'same' convolution (+bias), differentiable to any order (reference F.conv2d, quant_layer.py:80, as used
     under torch.autograd.grad(create_graph=True) by methods/bit_assign.py:88-114)."""
     y = _ConvF.apply(x, w)
-    return y if b is None else y + b.view(1, -1, 1, 1)
+    return y if b is None else _BiasAddDD.apply(y, b)
 
 
 def decoder_stack_dd(emb, spec, weights):
-    """Decoder forward (reference HNeRV.py:49-71 / NeRV.py:44-65) on the twice-differentiable convolution; PixelShuffle /
-    exact GELU / tanh go through PyTorch's own differentiable elementwise ops (not on the calibration hot path)."""
+    """Decoder forward (reference HNeRV.py:49-71 / NeRV.py:44-65), twice differentiable, every operator on this repo's HIP
+    kernels: the bilinear convolution family (_ConvF / _ConvD / _ConvWg), the bias broadcast, PixelShuffle, the exact-erf
+    GELU and OutImg's tanh with their first and second derivatives (nq_act_dd).  Only the NeRV channel -> space view of
+    layer 0 (NeRV.py:49-51: a reshape / permute, no arithmetic) is a PyTorch tensor view."""
     x = emb
     for l, ((k, r, act), (W, b)) in enumerate(zip(spec.layers, weights)):
         x = conv2d_dd(x, W, b)
         if l == 0 and spec.fc_hw != (1, 1):
             x = _space_from_channels(x, *spec.fc_hw)
         if r > 1:
-            x = torch.nn.functional.pixel_shuffle(x, r)
+            x = pixel_shuffle_dd(x, r)
         if act:
-            x = torch.nn.functional.gelu(x)
-    return torch.tanh(x) * 0.5 + 0.5 if spec.tanh_out else x
+            x = gelu_dd(x)
+    return tanh_out_dd(x) if spec.tanh_out else x
 
 
 def conv2d_fused(x, w, b, epilogue=EPI_PLAIN, r=1):

@@ -841,6 +841,49 @@ def test_conv2d_dd_second_order(ops, case):
         close(a, r, rtol=2e-3, atol=3e-5 * s)
 
 
+@pytest.mark.parametrize("r", (2, 3, 5))
+def test_elementwise_dd_kernels_second_order(ops, r):
+    """The twice-differentiable elementwise pieces of the decoder on their own kernels (round 4: PixelShuffle / GELU / tanh /
+    bias of ops.decoder_stack_dd went through ATen before): values, gradients and a Hessian-vector product -- the reference's
+    recipe, autograd.grad(create_graph=True) then .backward() (bit_assign.py:88-114) -- against torch in float64."""
+    g = torch.Generator().manual_seed(40 + r)
+    B, C, H, W = 2, 3, 4, 5
+    x0 = torch.randn(B, C * r * r, H, W, generator=g) * 1.5
+    b0 = torch.randn(C * r * r, generator=g)
+    v0 = torch.randn(B, C * r * r, H, W, generator=g)
+    go = torch.randn(B, C, H * r, W * r, generator=g)
+
+    def chain(x, b, dd):
+        if dd:
+            y = ops._BiasAddDD.apply(x, b)
+            return ops.tanh_out_dd(ops.gelu_dd(ops.pixel_shuffle_dd(y, r)))
+        y = x + b.view(1, -1, 1, 1)
+        return torch.tanh(F.gelu(F.pixel_shuffle(y, r))) * 0.5 + 0.5
+
+    res = []
+    for dd in (False, True):
+        dt, dev = (torch.float32, DEV) if dd else (torch.float64, "cpu")
+        x, b = x0.to(dev, dt).requires_grad_(True), b0.to(dev, dt).requires_grad_(True)
+        y = chain(x, b, dd)
+        loss = (y * go.to(dev, dt)).pow(2).sum()                      # non-linear in y, like the MSE criterion
+        gx, gb = torch.autograd.grad(loss, (x, b), create_graph=True)
+        prod = (gx * v0.to(dev, dt)).sum() + gb.sum()
+        prod.backward()
+        res.append([t.detach().cpu().double() for t in (y, gx, gb, x.grad, b.grad)])
+    for name, ref, got in zip(("y", "dx", "db", "Hv_x", "Hv_b"), *res):
+        scale = float(ref.abs().max())
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-5, atol=2e-6 * max(scale, 1.0), err_msg=name)
+    # PixelShuffle is a permutation: exact, and its inverse undoes it
+    xs = x0.to(DEV)
+    assert torch.equal(ops.pixel_shuffle_raw(xs, r).cpu(), F.pixel_shuffle(x0, r))
+    assert torch.equal(ops.pixel_shuffle_raw(ops.pixel_shuffle_raw(xs, r), r, inverse=True), xs)
+    with pytest.raises(NotImplementedError):                          # a third derivative is refused, not silently wrong
+        xg = x0.to(DEV).requires_grad_(True)
+        g1, = torch.autograd.grad(ops.gelu_dd(xg).sum(), xg, create_graph=True)
+        g2, = torch.autograd.grad(g1.sum(), xg, create_graph=True)
+        torch.autograd.grad(g2.sum(), xg)
+
+
 @pytest.mark.parametrize("mode", ("omega", "fisher_diag"))
 def test_sensitivity_criterion_matches_reference(ops, golden, mode):
     """methods.bit_assign.sensitivity_criterion on the GPU vs the values the reference's own function produced for the
