@@ -325,6 +325,18 @@ NQ_API int nq_l2_loss_tanh_head(const float* pred, const float* tgt, const uint8
                          float* dconv, float* db, float* ws, int B, int C, int64_t HW, int64_t mean_count, float gscale,
                          nq_stream_t stream);
 
+/* The decoder's 3-channel tanh head (HNeRV.py:42, 64-66; NeRV.py:37, 58-60; OutImg models/_layers.py:10-16) AND the loss
+ * tail of nq_l2_loss_tanh_head in one pass over the image (ABI v4): y (B,3,H,W) = tanh(conv3x3(x, w) + bias) * 0.5 + 0.5 is
+ * still written; loss, dconv and db as nq_l2_loss_tanh_head defines them (the same per-element arithmetic; the loss and db
+ * are summed per image strip and then in strip order: deterministic, last-bit different from the chunked sums of
+ * nq_l2_loss_tanh_head).  wt / ld: the fp32 forward operand of nq_weight_layouts for the (Cin -> 3, k = 3) head.
+ * ws: nq_head_forward_loss_ws_floats(B, H, W) floats.  NQ_ERR_UNSUPPORTED unless W % 4 == 0, ld % 4 == 0 and x < 4 GiB
+ * (callers then run nq_conv_forward + nq_l2_loss_tanh_head). */
+NQ_API int64_t nq_head_forward_loss_ws_floats(int B, int H, int W);
+NQ_API int nq_head_forward_loss(const float* x, const float* wt, int ld, const float* bias, float* y, const float* tgt,
+                         const uint8_t* cache_u8, const int64_t* idx, float* loss, float* dconv, float* db, float* ws, int B,
+                         int Cin, int H, int W, int64_t mean_count, float gscale, nq_stream_t stream);
+
 /* Per-frame PSNR pieces (utils.py:148-151): sse[f] = sum over one frame of (out-gt)^2, frames of frame_len floats. */
 NQ_API int nq_frame_sse(const float* out, const float* gt, float* sse, int64_t frames, int64_t frame_len, nq_stream_t stream);
 

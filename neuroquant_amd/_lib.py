@@ -130,6 +130,8 @@ def _load():
     sig("nq_l2_loss_tanh_head", I, P, P, P, P, P, P, P, P, I, I, L, L, F, P)
     sig("nq_frame_sse", I, P, P, P, L, L, P)
     sig("nq_gather_frames_u8", I, P, P, P, L, L, P)
+    sig("nq_head_forward_loss_ws_floats", L, I, I, I)
+    sig("nq_head_forward_loss", I, P, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, L, F, P)
     sig("nq_act_dd", I, P, P, P, P, L, I, P)
     sig("nq_pixel_shuffle", I, P, P, I, I, I, I, I, I, P)
     sig("nq_bias_add", I, P, P, P, I, I, L, P)
@@ -145,7 +147,7 @@ EXPORTS = (
     "nq_conv_wgrad3_slabs", "nq_conv_wgrad3_swapped_slabs", "nq_conv_wgrad_slabs", "nq_wgrad_reduce_multi",
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",
     "nq_channel_sum", "nq_l2_loss_tanh_head", "nq_frame_sse", "nq_gather_frames_u8",
-    "nq_act_dd", "nq_pixel_shuffle", "nq_bias_add",
+    "nq_act_dd", "nq_pixel_shuffle", "nq_bias_add", "nq_head_forward_loss_ws_floats", "nq_head_forward_loss",
 )
 
 _lib = None

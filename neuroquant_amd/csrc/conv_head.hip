@@ -164,13 +164,26 @@ struct HeadFwd2Args {
   int B, Cin, H, W, ld, strips, rblocks;
   unsigned x_bytes;
 };
+// Round 4: the loss tail fused behind the head (LOSS = true).  The wave that owns a strip of the image has every output pixel of
+// it in registers: lp_loss (quantizer.py:66-71), the tanh backward of OutImg (_layers.py:10-16) and the head's bias gradient
+// are computed there -- the arithmetic of l2_tanh_head_stage1 per element -- and the image is still written (evaluation and
+// the autograd node keep their tensor).  Per wave: {sum (p-t)^2, sum dconv[c0], [c1], [c2]} -> ws[4*wave id ..]; head_loss_stage2
+// adds them in wave-id order (deterministic; another summation order than l2_tanh_head_stage1's 4096-element chunks).
+struct HeadLossArgs {
+  const float* tgt;          // float target (B,3,H,W) ...
+  const uint8_t* cache;      // ... or the uint8 frame cache (N,3,H,W) with
+  const int64_t* idx;        //     the batch's frame indices
+  float* dconv;              // gradient at the head conv's output (B,3,H,W)
+  float* ws;                 // 4 floats per wave
+  float gcoef;               // 2 / (B*H*W) * gscale
+};
 
 // (the pointers are kernel PARAMETERS with __restrict__: the compiler then knows that the stores to y cannot change x / wt)
 // wt[(ci*9 + tap)*ld + co], zero for co >= CO (nq_weight_layouts)
-template <int R, int NCO, bool TANH>
+template <int R, int NCO, bool TANH, bool LOSS = false>
 __global__ __launch_bounds__(256) void head_fwd2_kernel(const float* __restrict__ x_, const float* __restrict__ wt,
                                                         const float* __restrict__ bias, float* __restrict__ y_,
-                                                        HeadFwd2Args a) {
+                                                        HeadFwd2Args a, HeadLossArgs la = HeadLossArgs{}) {
   constexpr int KS = 3, KK = 9, NR = R + 2;
   constexpr unsigned OOB = 0xFFFFFF00u;
   // (the wave index through readfirstlane: everything derived from it -- frame, strip, row block, the scalar offsets of the
@@ -282,11 +295,21 @@ __global__ __launch_bounds__(256) void head_fwd2_kernel(const float* __restrict_
   float bv[NCO];
 #pragma unroll
   for (int co = 0; co < NCO; ++co) bv[co] = bias ? bias[co] : 0.f;
+  float lsum = 0.f, gsum[NCO];
+#pragma unroll
+  for (int co = 0; co < NCO; ++co) gsum[co] = 0.f;
+  __amdgpu_buffer_rsrc_t rs_d = rs_y;
+  int64_t tbase = 0;   // element offset of (frame, channel 0) in the target
+  if constexpr (LOSS) {
+    rs_d = __builtin_amdgcn_make_buffer_rsrc(la.dconv, 0, (int)((unsigned)a.B * NCO * HWb), 0x00020000);
+    tbase = (la.cache ? la.idx[b] : (int64_t)b) * NCO * (int64_t)H * W;
+  }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int oy = y0 + r;
+    const bool in = oy < H && gx < W;   // (W % 4 == 0: a quad is inside or outside as a whole)
     // bounds-checked buffer stores (an out-of-range offset for rows / columns outside the image): no branch
-    const unsigned so = (oy < H && gx < W) ? ((unsigned)b * NCO * (unsigned)H + (unsigned)oy) * Wb + (unsigned)gx * 4u : OOB;
+    const unsigned so = in ? ((unsigned)b * NCO * (unsigned)H + (unsigned)oy) * Wb + (unsigned)gx * 4u : OOB;
 #pragma unroll
     for (int co = 0; co < NCO; ++co) {
       f32x4 o;
@@ -297,7 +320,58 @@ __global__ __launch_bounds__(256) void head_fwd2_kernel(const float* __restrict_
       }
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, o), rs_y,
                                              so == OOB ? OOB : so + (unsigned)co * HWb, 0, 0);
+      if constexpr (LOSS) {
+        f32x4 t4 = {0.f, 0.f, 0.f, 0.f};
+        if (in) {
+          const int64_t te = tbase + ((int64_t)co * H + oy) * W + gx;
+          if (la.cache) {
+            const uchar4 u = *reinterpret_cast<const uchar4*>(la.cache + te);   // gx % 4 == 0: aligned
+            t4 = f32x4{(float)u.x / 255.f, (float)u.y / 255.f, (float)u.z / 255.f, (float)u.w / 255.f};
+          } else {
+            t4 = *reinterpret_cast<const f32x4*>(la.tgt + te);
+          }
+        }
+        f32x4 dc;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {   // l2_tanh_head_stage1, element by element
+          const float d = o[p] - t4[p];
+          const float g = la.gcoef * d;
+          const float u = 2.f * o[p] - 1.f;
+          const float rr = g * 0.5f * (1.f - u * u);
+          dc[p] = rr;
+          if (in) {
+            lsum += d * d;
+            gsum[co] += rr;
+          }
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, dc), rs_d,
+                                               so == OOB ? OOB : so + (unsigned)co * HWb, 0, 0);
+      }
     }
+  }
+  if constexpr (LOSS) {
+    lsum = nq_wave_sum(lsum);
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) gsum[co] = nq_wave_sum(gsum[co]);
+    if (lane == 0) {
+      float* w4 = la.ws + (int64_t)wid * 4;
+      w4[0] = lsum;
+#pragma unroll
+      for (int co = 0; co < NCO && co < 3; ++co) w4[1 + co] = gsum[co];
+    }
+  }
+}
+
+// block 0: loss = scale * sum over waves; block 1 + c: db[c] -- fixed order (thread-strided partial sums, then the block sum)
+__global__ __launch_bounds__(256) void head_loss_stage2(const float* __restrict__ ws, int waves, float scale,
+                                                        float* __restrict__ loss, float* __restrict__ db) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < waves; i += 256) acc += ws[(int64_t)i * 4 + blockIdx.x];
+  const float s = nq_block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0) loss[0] = 0.f + s * scale;
+    else db[blockIdx.x - 1] = s;
   }
 }
 
@@ -629,6 +703,33 @@ int nq_head_forward(const float* x, const float* wt, int ld, const float* bias, 
     case 3: hipLaunchKernelGGL(head_fwd_kernel<3>, g, blk, 0, st, x, wt, ld, bias, y, Cin, H, W, Cout, epi, tiles_x); break;
     default: hipLaunchKernelGGL(head_fwd_kernel<5>, g, blk, 0, st, x, wt, ld, bias, y, Cin, H, W, Cout, epi, tiles_x); break;
   }
+  return nq_launch_status();
+}
+
+// The 3-channel tanh head and the loss tail in ONE pass (include/nq_hip.h: nq_head_forward_loss).
+int64_t nq_head_forward_loss_ws_floats(int B, int H, int W) {
+  if (B <= 0 || H <= 0 || W <= 0) return 0;
+  return (int64_t)B * ((W + 255) / 256) * ((H + 3) / 4) * 4;
+}
+
+int nq_head_forward_loss(const float* x, const float* wt, int ld, const float* bias, float* y, const float* tgt,
+                         const uint8_t* cache_u8, const int64_t* idx, float* loss, float* dconv, float* db, float* ws, int B,
+                         int Cin, int H, int W, int64_t mean_count, float gscale, nq_stream_t stream) {
+  if (!x || !wt || !y || !loss || !dconv || !db || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || mean_count <= 0) return NQ_ERR_INVALID;
+  if ((tgt == nullptr) == (cache_u8 == nullptr) || (cache_u8 && !idx)) return NQ_ERR_INVALID;
+  if ((W & 3) != 0 || (ld & 3) != 0 || (int64_t)B * Cin * H * W * 4 >= 0xFFFFFF00ll) return NQ_ERR_UNSUPPORTED;
+  constexpr int R = 4;
+  HeadFwd2Args a;
+  a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.ld = ld;
+  a.strips = (W + 255) / 256; a.rblocks = (H + R - 1) / R;
+  a.x_bytes = (unsigned)((int64_t)B * Cin * H * W * 4);
+  HeadLossArgs la;
+  la.tgt = tgt; la.cache = cache_u8; la.idx = idx; la.dconv = dconv; la.ws = ws;
+  la.gcoef = (float)(2.0 / (double)mean_count) * gscale;
+  const int waves = B * a.strips * a.rblocks;
+  hipStream_t st = nq_s(stream);
+  hipLaunchKernelGGL((head_fwd2_kernel<R, 3, true, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, x, wt, bias, y, a, la);
+  hipLaunchKernelGGL(head_loss_stage2, dim3(4), dim3(256), 0, st, ws, waves, (float)(1.0 / (double)mean_count), loss, db);
   return nq_launch_status();
 }
 

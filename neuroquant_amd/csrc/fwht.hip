@@ -12,8 +12,23 @@
 
 namespace {
 
-constexpr int TPB = 256;
-constexpr int LDS_FLOATS = 8192 + 1024;
+// Workgroup size / tile / columns per workgroup (compile-time; A/B of whole libraries inside a NeRV-3M + Hadamard iteration,
+// us forward / backward launch): 256 threads, 8192-float tile, ~32 columns (rounds 2-3) 23.0 / 24.1; 512, 8192, 32: 17.5 / 20.1;
+// 1024, 8192, 32: 19.6 / 22.0; 512, 8192, 16: 16.3 / 17.9; 256 or 512, 4096, 16: 18.6 / 19.4-20.2; 512, 2560, 9: 19.9 / 21.4.
+// The phases of a tile (load | three butterfly passes | store) are separated by barriers, so a launch lasts as long as the
+// longest workgroup's chain: twice the waves halve the chain's per-thread work, smaller tiles did not help further.
+#ifndef NQ_FWHT_TPB
+#define NQ_FWHT_TPB 512
+#endif
+constexpr int TPB = NQ_FWHT_TPB;
+#ifndef NQ_FWHT_TILE
+#define NQ_FWHT_TILE 8192
+#endif
+#ifndef NQ_FWHT_COLS
+#define NQ_FWHT_COLS 16
+#endif
+constexpr int TILE = NQ_FWHT_TILE;             // floats of a workgroup's tile (n * columns)
+constexpr int LDS_FLOATS = TILE + 1024;    // n * (columns + 1) floats, n <= 1024
 
 // G butterfly stages s0 .. s0+G-1 in one pass: a thread takes the 2^G rows that differ in bits s0 .. s0+G-1 of one column
 template <int G>
@@ -183,8 +198,8 @@ extern "C" int nq_fwht(const float* x, float* y, int64_t outer, int n, int64_t i
   if (n > 1024) return NQ_ERR_UNSUPPORTED;
   int log2n = 0;
   while ((1 << log2n) < n) ++log2n;
-  if ((int64_t)n * inner > 8192) {   // one outer row does not fit the LDS tile: column-gather variant
-    int TC = 8192 / n;
+  if ((int64_t)n * inner > TILE) {   // one outer row does not fit the LDS tile: column-gather variant
+    int TC = TILE / n;
     if (TC > 32) TC = 32;
     int64_t ncols = outer * inner;
     int64_t blocks = (ncols + TC - 1) / TC;
@@ -193,8 +208,8 @@ extern "C" int nq_fwht(const float* x, float* y, int64_t outer, int n, int64_t i
                        n_in, n_out, TC, sqrtf((float)n));
     return nq_launch_status();
   }
-  int OPB = (int)(8192 / ((int64_t)n * inner));   // outer rows per workgroup
-  const int cap = (int)((32 + inner - 1) / inner); // ~32 columns per workgroup keeps the grid large
+  int OPB = (int)(TILE / ((int64_t)n * inner));   // outer rows per workgroup
+  const int cap = (int)((NQ_FWHT_COLS + inner - 1) / inner); // ~32 columns per workgroup keeps the grid large
   if (OPB > cap) OPB = cap;
   if (OPB < 1) OPB = 1;
   int64_t blocks = (outer + OPB - 1) / OPB;
@@ -221,15 +236,15 @@ extern "C" int nq_fwht_multi(const nq_fwht_seg* segs, int nseg, nq_stream_t stre
     if (!h.x || !h.y || h.x == h.y || h.outer <= 0 || h.inner <= 0 || h.n <= 0 || (h.n & (h.n - 1)) != 0) return NQ_ERR_INVALID;
     if (h.n_in <= 0 || h.n_in > h.n || h.n_out <= 0 || h.n_out > h.n) return NQ_ERR_INVALID;
     if (h.n > 1024) return NQ_ERR_UNSUPPORTED;
-    if ((int64_t)h.n * h.inner > 8192) {   // long rows: the single-tensor column-gather variant
+    if ((int64_t)h.n * h.inner > TILE) {   // long rows: the single-tensor column-gather variant
       int rc = nq_fwht(h.x, h.y, h.outer, h.n, h.inner, h.n_in, h.n_out, stream);
       if (rc != NQ_OK) return rc;
       continue;
     }
     int log2n = 0;
     while ((1 << log2n) < h.n) ++log2n;
-    int OPB = (int)(8192 / ((int64_t)h.n * h.inner));
-    const int cap = (int)((32 + h.inner - 1) / h.inner);
+    int OPB = (int)(TILE / ((int64_t)h.n * h.inner));
+    const int cap = (int)((NQ_FWHT_COLS + h.inner - 1) / h.inner);
     if (OPB > cap) OPB = cap;
     if (OPB < 1) OPB = 1;
     const int64_t nb = (h.outer + OPB - 1) / OPB;

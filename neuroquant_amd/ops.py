@@ -1062,6 +1062,56 @@ def arena_reduced(img):
     return bool(getattr(getattr(img, "grad_fn", None), "nq_arena_reduced", False))
 
 
+# Fused loss tail (round 4): inside `with ops.fused_head_loss(...)` a tanh-headed decoder node whose head is the 3-channel 3x3
+# convolution runs nq_head_forward_loss -- the head AND lp_loss / tanh backward / bias gradient in one pass over the image --
+# and leaves the result in its hand-over slot; l2_loss_head_grad then returns it without launching anything.  Per-thread
+# state like the arena hook; a decoder that cannot use it simply ignores the request.
+_LOSS_TLS = threading.local()
+
+
+@contextlib.contextmanager
+def fused_head_loss(tgt=None, cache_u8=None, idx=None):
+    """Request the fused loss tail for decoder forwards in the body: target = float frames `tgt` (B,3,H,W) or frames
+    cache_u8[idx] / 255 of the uint8 frame cache."""
+    prev = getattr(_LOSS_TLS, "req", None)
+    _LOSS_TLS.req = None if os.environ.get("NQ_FUSED_HEAD_LOSS", "1") == "0" else (tgt, cache_u8, idx)
+    try:
+        yield
+    finally:
+        _LOSS_TLS.req = prev
+
+
+def head_forward_loss_raw(x, wt, dims, bias, cout, k, tgt=None, cache_u8=None, idx=None):
+    """nq_head_forward_loss: -> (img, loss, dconv, db) or None when the fused kernel does not apply."""
+    B, cin, H, W = x.shape
+    if cout != 3 or k != 3 or (W & 3) or (dims[1] & 3) or os.environ.get("NQ_HEAD_FWD") == "1":
+        return None
+    if cache_u8 is not None:
+        if not cache_u8.is_cuda or cache_u8.dtype != torch.uint8 or not cache_u8.is_contiguous() \
+                or tuple(cache_u8.shape[1:]) != (cout, H, W) or idx is None or idx.numel() != B:
+            return None
+        idx = idx.to(device=x.device, dtype=torch.int64).contiguous()
+        tgt = None
+    elif tgt is not None:
+        if not tgt.is_cuda or tgt.dtype != torch.float32 or tuple(tgt.shape) != (B, cout, H, W):
+            return None
+        tgt = tgt.contiguous()
+    else:
+        return None
+    y = torch.empty((B, cout, H, W), device=x.device, dtype=torch.float32)
+    dconv = torch.empty_like(y)
+    loss = torch.empty((), device=x.device, dtype=torch.float32)
+    db = torch.empty(cout, device=x.device, dtype=torch.float32)
+    ws = torch.empty(_q("nq_head_forward_loss_ws_floats", B, H, W), device=x.device, dtype=torch.float32)
+    rc = _timed(("conv_igemm", k, cin, cout, H, W, B, EPI_TANH),
+                lambda: L.lib().nq_head_forward_loss(_p(x), _p(wt), dims[1], _p(bias), _p(y), _p(tgt), _p(cache_u8), _p(idx), _p(loss),
+                                                     _p(dconv), _p(db), _p(ws), B, cin, H, W, B * H * W, 1.0, _stream()))
+    if rc == -2:     # NQ_ERR_UNSUPPORTED: the caller runs the separate kernels
+        return None
+    L.check(rc, "head_forward_loss")
+    return y, loss, dconv, db
+
+
 _SIDE_STREAMS = {}
 
 
@@ -1134,7 +1184,13 @@ class _DecoderStackFn(Function):
                 epi = EPI_PS
             else:
                 epi = EPI_PLAIN
-            if use3:
+            fused_loss = None
+            if last and epi == EPI_TANH and not use3 and getattr(_LOSS_TLS, "req", None) is not None:
+                tgt_, cache_, idx_ = _LOSS_TLS.req
+                fused_loss = head_forward_loss_raw(x, wt, dims, b, cout, k, tgt_, cache_, idx_)
+            if fused_loss is not None:
+                y, z = fused_loss[0], None
+            elif use3:
                 y, z = conv3_forward_raw(x, wt3, b, cout, k, epi, r)
             else:
                 y, z = conv_forward_raw(x, wt, dims, b, cout, k, epi, r, in_gelu=in_gelu)
@@ -1155,6 +1211,9 @@ class _DecoderStackFn(Function):
         # when the forward ran, whether backward handed the arena to it, and the hand-over slot of the fused loss tail
         ctx.nq_arena, ctx.nq_arena_reduced = _arena_state(), False
         ctx.nq_head = _HeadHandoff() if spec.tanh_out else None
+        if fused_loss is not None:   # the loss tail already ran behind the head: l2_loss_head_grad hands it out
+            ctx.nq_head.loss, ctx.nq_head.dconv, ctx.nq_head.db = fused_loss[1], fused_loss[2], fused_loss[3]
+            ctx.nq_head.version = fused_loss[2]._version
         return x
 
     @staticmethod
@@ -1185,6 +1244,10 @@ def _decoder_backward_steps(ctx, g_img):
     g = _dev(g_img, "grad")
     head_db = None
     head = ctx.nq_head
+    if head is not None and head.loss is not None:
+        # the fused loss tail ran behind the head but nobody took its result (l2_loss_head_grad was not called): the incoming
+        # gradient is an ordinary d(loss)/d(image)
+        head.dconv = head.db = head.loss = None
     if head is not None and head.dconv is not None:
         # l2_loss_head_grad handed over the gradient at the head conv's OUTPUT (tanh backward applied) and the head's
         # bias gradient.  Anything but that very tensor, unmodified, cannot be continued from: say so loudly.
@@ -1414,10 +1477,10 @@ class _HeadHandoff:
     l2_loss_head_grad fills it with the gradient at the head conv's output and the head's bias gradient, the node's
     backward takes them when the incoming gradient is that very tensor (`version` = its in-place edit counter at the
     hand-over: an edited gradient is still continued from, but the bias gradient is summed again)."""
-    __slots__ = ("dconv", "db", "version")
+    __slots__ = ("dconv", "db", "version", "loss")
 
     def __init__(self):
-        self.dconv = self.db = self.version = None
+        self.dconv = self.db = self.version = self.loss = None
 
 
 def l2_loss_tanh_head_raw(pred, tgt=None, cache_u8=None, idx=None):
@@ -1463,6 +1526,9 @@ def l2_loss_head_grad(pred, tgt=None, cache_u8=None, idx=None, node=None):
     head = getattr(node if node is not None else pred.grad_fn, "nq_head", None)
     if not isinstance(head, _HeadHandoff) or os.environ.get("NQ_FUSED_LOSS", "1") == "0":
         return None
+    if head.loss is not None:   # computed behind the head convolution (ops.fused_head_loss): nothing to launch
+        loss, head.loss = head.loss, None
+        return loss, head.dconv
     out = l2_loss_tanh_head_raw(pred, tgt, cache_u8, idx)
     if out is None:
         return None

@@ -324,12 +324,15 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                     for i, L in enumerate(layers):
                         L._finish(fq[2 * i], fq[2 * i + 1])
             node = None
-            if staged is None:
-                img_out, _, _ = model(inputs)
-            else:   # the same decoder node, driven by hand (weights as model._wb_override set them, in layer order)
-                spec, provs = fused_stack
-                img_out, node = ops.decoder_forward_manual(inputs, spec, [p() for p in provs],
-                                                           two_phase=os.environ.get("NQ_DP_OVERLAP", "1") != "0")
+            # (the loss tail runs behind the head convolution when the decoder is the fused stack: ops.fused_head_loss)
+            loss_req = ops.fused_head_loss(cache_u8=img[0], idx=img[1]) if isinstance(img, tuple) else ops.fused_head_loss(tgt=img)
+            with loss_req:
+                if staged is None:
+                    img_out, _, _ = model(inputs)
+                else:   # the same decoder node, driven by hand (weights as model._wb_override set them, in layer order)
+                    spec, provs = fused_stack
+                    img_out, node = ops.decoder_forward_manual(inputs, spec, [p() for p in provs],
+                                                               two_phase=os.environ.get("NQ_DP_OVERLAP", "1") != "0")
             # lp_loss p=2 (quantizer.py:66-71) and its gradient; behind a tanh-headed fused decoder the loss kernel also
             # applies the tanh backward and sums the head's bias gradient (ops.l2_loss_head_grad), reading the target
             # straight from the uint8 frame cache when the batch came as (frames_u8, indices)

@@ -1021,6 +1021,45 @@ def test_fused_loss_tail_equals_separate_kernels(ops, u8):
     assert ops.l2_loss_tanh_head_raw(odd, tgt=torch.rand(2, 3, 17, 23, generator=g).to(DEV)) is None
 
 
+@pytest.mark.parametrize("shape", [(2, 37, 640, 1280), (1, 24, 320, 640), (3, 5, 17, 36), (2, 9, 64, 1028)])
+@pytest.mark.parametrize("u8", [False, True])
+def test_head_forward_with_fused_loss_tail(ops, shape, u8):
+    """nq_head_forward_loss (round 4: the loss tail behind the head convolution, one pass over the image) against the two
+    launches it replaces: the image bit-identical to the streaming head kernel, dconv bit-identical to nq_l2_loss_tanh_head's
+    (same per-element arithmetic on the same image), loss and bias gradient to summation-order tolerance (per-strip sums
+    instead of 4096-element chunks) and against float64."""
+    B, cin, H, W = shape
+    g = torch.Generator().manual_seed(B * 1000 + cin + W)
+    x = torch.randn(B, cin, H, W, generator=g).to(DEV)
+    w = (torch.randn(3, cin, 3, 3, generator=g) / math.sqrt(cin * 9)).to(DEV)
+    b = (torch.randn(3, generator=g) * 0.1).to(DEV)
+    n = B + 2
+    cache = torch.randint(0, 256, (n, 3, H, W), generator=g, dtype=torch.uint8).to(DEV)
+    idx = torch.randperm(n, generator=g)[:B].to(DEV)
+    tgt = ops.gather_frames_u8(cache, idx)
+    wt, dims, _, _ = ops.weight_layouts(w, False)
+    img = ops.conv_forward_raw(x, wt, dims, b, 3, 3, ops.EPI_TANH, 1)[0]
+    kw = dict(cache_u8=cache, idx=idx) if u8 else dict(tgt=tgt)
+    out = ops.head_forward_loss_raw(x, wt, dims, b, 3, 3, **kw)
+    assert out is not None
+    y, loss, dconv, db = out
+    assert torch.equal(y, img)
+    ref = ops.l2_loss_tanh_head_raw(img, **kw) if (H * W) % 4096 == 0 else None
+    pd, td = img.double(), tgt.double()
+    d = pd - td
+    loss64 = float((d * d).sum() / (B * H * W))
+    dconv64 = (2.0 / (B * H * W)) * d * 0.5 * (1 - (2 * pd - 1) ** 2)
+    if ref is not None:
+        assert torch.equal(dconv, ref[1])
+        close(loss, ref[0], rtol=2e-6)
+        close(db, ref[2], rtol=1e-5, atol=1e-6 * float(ref[2].abs().max()) + 1e-9)
+    close(loss, loss64, rtol=5e-6)
+    close(dconv, dconv64, rtol=1e-5, atol=1e-6 * float(dconv64.abs().max()))
+    close(db, dconv64.sum((0, 2, 3)), rtol=1e-4, atol=2e-5 * float(dconv64.abs().sum((0, 2, 3)).max()))
+    y2, loss2, dconv2, db2 = ops.head_forward_loss_raw(x, wt, dims, b, 3, 3, **kw)
+    assert torch.equal(loss, loss2) and torch.equal(db, db2) and torch.equal(dconv, dconv2)    # deterministic
+
+
 @pytest.mark.parametrize("shape", [(2, 37, 640, 1280), (1, 24, 320, 640), (3, 5, 17, 36), (1, 37, 7, 260), (2, 9, 64, 1028)])
 @pytest.mark.parametrize("epi_tanh", [True, False])
 def test_head_forward_streaming_kernel(ops, shape, epi_tanh, monkeypatch):
