@@ -18,6 +18,8 @@ int nq_conv3_nstk_k5(int);
 int nq_conv_flat3_plan(int, int, int, int, int, int, int*, int*, int*, int*);
 int nq_conv_flat3(const float*, const void*, const float*, float*, float*, const float*, float*, int, int, int, int, int, int, int, int,
                   int, int, int, int, hipStream_t);
+int nq_conv_wgrad_flat3_ok(int, int, int, int, int, int);
+int nq_conv_wgrad_flat3(const float*, const float*, float*, float*, int, int, int, int, int, int, hipStream_t);
 int nq_conv_wgrad3_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 int nq_conv_wgrad3_k5(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 }
@@ -481,6 +483,7 @@ int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* 
 
 int nq_conv_wgrad3_supported(int B, int Cin, int H, int W, int Cout, int k) {
   if (!(k == 3 || k == 5) || B <= 0 || Cin <= 0 || Cout <= 4) return 0;
+  if (nq_conv_wgrad_flat3_ok(B, Cin, H, W, Cout, k)) return 1;   // few-pixel layers: conv_wgrad_flat3.hip (no slabs)
   return (int64_t)((W + 31) / 32) * H * B >= 128;  // enough 32-pixel segments to split over
 }
 
@@ -493,6 +496,7 @@ int nq_conv_wgrad3_plan(int B, int Cin, int H, int W, int Cout, int k, int* mi, 
 
 int64_t nq_conv_wgrad3_ws_floats(int B, int Cin, int H, int W, int Cout, int k) {
   if (!(k == 3 || k == 5) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  if (nq_conv_wgrad_flat3_ok(B, Cin, H, W, Cout, k)) return 4;   // no slabs (a token workspace keeps the pointer non-NULL)
   Wg3Plan p = plan_wgrad3(B, Cin, H, W, Cout, k);
   return (int64_t)p.nsplit * p.co_pad * ((int64_t)p.n_pad + 1);
 }
@@ -557,6 +561,11 @@ static int conv_wgrad3_impl(const float* x, const float* dy, float* dw, float* d
   if (!x || !dy || !dw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
   if (!(k == 3 || k == 5)) return NQ_ERR_UNSUPPORTED;
   if ((int64_t)Cout * H * W >= (1ll << 31) || (int64_t)Cin * H * W >= (1ll << 31)) return NQ_ERR_UNSUPPORTED;
+  if (swap_kk == 0 && nq_conv_wgrad_flat3_ok(B, Cin, H, W, Cout, k)) {
+    // few-pixel layer: every output block is owned by one wave for the whole K range -- dw / db are final, nothing pending
+    if (seg) *seg = nq_wgr_seg{nullptr, nullptr, dw, db, Cout, Cin * k * k, 0, 0, 0, 0, 1};
+    return nq_conv_wgrad_flat3(x, dy, dw, db, B, Cin, H, W, Cout, k, nq_s(stream));
+  }
   Wg3Plan p = plan_wgrad3(B, Cin, H, W, Cout, k);
   float* slab = ws;
   float* slab_db = ws + (int64_t)p.nsplit * p.co_pad * p.n_pad;

@@ -310,7 +310,11 @@ def test_conv_bf16x3(ops, case):
                                   (2, 20, 33, 100, 96, 3), (3, 9, 16, 64, 36, 3), (1, 37, 40, 64, 12, 3),
                                   # enough 32-pixel segments per workgroup for the producer/consumer kernel (8 waves, one
                                   # workgroup per CU): dec5 / dec4 channel geometry, ragged last segment in the second
-                                  (2, 44, 48, 224, 148, 5), (1, 53, 66, 216, 176, 5), (2, 36, 128, 256, 96, 3)])
+                                  (2, 44, 48, 224, 148, 5), (1, 53, 66, 216, 176, 5), (2, 36, 128, 256, 96, 3),
+                                  # few-pixel layers (conv_wgrad_flat3.hip: all pixels of all frames = the K dimension, no split-K, no
+                                  # slabs): HNeRV dec2, NeRV dec1 / dec2, k = 5, a ragged last k-step (72 pixels), ragged tiles
+                                  (2, 77, 10, 20, 1024, 3), (2, 145, 2, 4, 1800, 3), (2, 72, 10, 20, 576, 3), (1, 30, 8, 8, 100, 5),
+                                  (3, 40, 4, 6, 200, 3)])
 def test_wgrad_bf16x3(ops, case):
     """bf16x3 weight/bias gradient vs float64 (error at the fp32 level relative to the gradient scale); deterministic."""
     B, Cin, H, W, Cout, k = case
@@ -340,6 +344,11 @@ def test_few_pixel_layers_take_the_flat_kernel():
         else:
             assert ws % (B * cout * H * W) == 0
     assert lib.nq_conv_forward3_ws_floats(2, 44, 320, 640, 148, 5) == 0
+    # the weight gradients of the deep layers leave no slabs either (conv_wgrad_flat3.hip): a token workspace
+    for B, cin, H, W, cout, k in [(2, 77, 10, 20, 1024, 3), (2, 145, 2, 4, 1800, 3), (2, 72, 10, 20, 576, 3)]:
+        assert lib.nq_conv_wgrad3_supported(B, cin, H, W, cout, k) == 1
+        assert lib.nq_conv_wgrad3_ws_floats(B, cin, H, W, cout, k) == 4
+    assert lib.nq_conv_wgrad3_ws_floats(2, 44, 320, 640, 148, 5) > 1 << 20
 
 
 def test_wgrad_swapped_roles_small_cout(ops):
