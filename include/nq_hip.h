@@ -178,6 +178,33 @@ typedef struct nq_fwht_seg {
 } nq_fwht_seg;
 NQ_API int nq_fwht_multi(const nq_fwht_seg* segs, int nseg, nq_stream_t stream);
 
+/* The AdaRound fake-quant fused with the transform (ABI v4; QuantModule.forward with hadamard=True, quant_layer.py:70-71, and
+ * its backward + Adam, calib_model.py:170-226): one launch per direction for all layers of a decoder.
+ *   nq_adaround_fwht_multi        y = H(Q(x))[:, :c_in] per weight tensor (x, alpha: (outer, n, inner) transform-domain weight and
+ *                                 its rounding variables; y: (outer, c_in, inner)); a segment with n == 0 is a plain tensor
+ *                                 (a bias: y = Q(x), outer * inner elements, one scalar delta / zp)
+ *   nq_fwht_adaround_adam_multi   g = H(pad(gy)) (gy: (outer, c_in, inner)), then d(alpha) (+ regulariser gradient, reg_weight)
+ *                                 and Adam's update of alpha / m / v in place; scalars and `dyn` as nq_adaround_adam_multi
+ * Bit-identical to nq_adaround_forward_multi + nq_fwht_multi and to nq_fwht_multi + nq_adaround_adam_multi (same butterflies,
+ * same per-element arithmetic); the transform-domain tensors no longer cross HBM between the two.  Rows with n * inner >
+ * 8192 are NQ_ERR_UNSUPPORTED (callers use the separate launches). */
+typedef struct nq_fq_fwht_seg {
+  const float* x;
+  float* alpha;
+  const float* delta;
+  const float* zp;
+  float* m;          /* backward only */
+  float* v;
+  const float* gy;   /* backward only */
+  float* y;          /* forward only */
+  int64_t outer, inner;
+  int n, c_in, per_row, n_levels, soft;
+  float reg_weight;
+} nq_fq_fwht_seg;
+NQ_API int nq_adaround_fwht_multi(const nq_fq_fwht_seg* segs, int nseg, nq_stream_t stream);
+NQ_API int nq_fwht_adaround_adam_multi(const nq_fq_fwht_seg* segs, int nseg, float reg_b, float step_size, float beta1, float beta2,
+                                float eps, float bc2_sqrt, const float* dyn, nq_stream_t stream);
+
 /* ---------------------------------------------------------------- convolution side ------------ */
 
 /* Re-layout an OIHW weight (Cout,Cin,k,k) into the two GEMM operands the conv kernels read:

@@ -54,6 +54,13 @@ class WgrSeg(Structure):
                 ("co_pad", c_int), ("n_pad", c_int), ("nsplit", c_int), ("swap_kk", c_int), ("sg", c_int)]
 
 
+class FqFwhtSeg(Structure):
+    """nq_fq_fwht_seg (include/nq_hip.h): one tensor of a launch that fuses the AdaRound fake-quant with the Hadamard transform."""
+    _fields_ = [("x", c_void_p), ("alpha", c_void_p), ("delta", c_void_p), ("zp", c_void_p), ("m", c_void_p), ("v", c_void_p),
+                ("gy", c_void_p), ("y", c_void_p), ("outer", c_int64), ("inner", c_int64), ("n", c_int), ("c_in", c_int),
+                ("per_row", c_int), ("n_levels", c_int), ("soft", c_int), ("reg_weight", c_float)]
+
+
 class AdamSeg(Structure):
     """nq_adam_seg (include/nq_hip.h)."""
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64)]
@@ -130,6 +137,8 @@ def _load():
     sig("nq_l2_loss_tanh_head", I, P, P, P, P, P, P, P, P, I, I, L, L, F, P)
     sig("nq_frame_sse", I, P, P, P, L, L, P)
     sig("nq_gather_frames_u8", I, P, P, P, L, L, P)
+    sig("nq_adaround_fwht_multi", I, POINTER(FqFwhtSeg), I, P)
+    sig("nq_fwht_adaround_adam_multi", I, POINTER(FqFwhtSeg), I, F, F, F, F, F, F, P, P)
     sig("nq_head_forward_loss_ws_floats", L, I, I, I)
     sig("nq_head_forward_loss", I, P, P, I, P, P, P, P, P, P, P, P, P, I, I, I, I, L, F, P)
     sig("nq_act_dd", I, P, P, P, P, L, I, P)
@@ -148,6 +157,7 @@ EXPORTS = (
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",
     "nq_channel_sum", "nq_l2_loss_tanh_head", "nq_frame_sse", "nq_gather_frames_u8",
     "nq_act_dd", "nq_pixel_shuffle", "nq_bias_add", "nq_head_forward_loss_ws_floats", "nq_head_forward_loss",
+    "nq_adaround_fwht_multi", "nq_fwht_adaround_adam_multi",
 )
 
 _lib = None

@@ -92,13 +92,25 @@ __device__ __forceinline__ void wl3_tile(const WL3& p, int c, int g16, float* __
   const int Ra = p.transposed ? p.Cin : p.Cout;            // valid extent of the row index (stored tensor's dim 0)
   const int Cb = p.transposed ? p.Cout : p.Cin;            // stored tensor's dim 1
   const int a0 = p.transposed ? c * 16 : g16 * 16, b0 = p.transposed ? g16 * 16 : c * 16;
-#pragma unroll 5
-  for (int e = tid; e < 16 * 16 * KK; e += 256) {
-    const int a = e / (16 * KK), rem = e - a * (16 * KK);
-    const int bb = rem / KK;
-    float v = 0.f;
-    if (a0 + a < Ra && b0 + bb < Cb) v = p.w[((int64_t)(a0 + a) * Cb + b0) * KK + rem];
-    T[a * RS + rem] = v;
+  // all KK loads of a thread in flight together (branch-free: an out-of-range element reads element 0 and is zeroed
+  // afterwards) -- with a conditional load the compiler waited for each group of five before issuing the next
+  {
+    float v[KK];
+#pragma unroll
+    for (int j = 0; j < KK; ++j) {
+      const int e = tid + j * 256;
+      const int a = e / (16 * KK), rem = e - a * (16 * KK);
+      const int bb = rem / KK;
+      const bool ok = a0 + a < Ra && b0 + bb < Cb;
+      const float t = p.w[ok ? ((int64_t)(a0 + a) * Cb + b0) * KK + rem : 0];
+      v[j] = ok ? t : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < KK; ++j) {
+      const int e = tid + j * 256;
+      const int a = e / (16 * KK), rem = e - a * (16 * KK);
+      T[a * RS + rem] = v[j];
+    }
   }
   __syncthreads();
   const int MT = p.MT;

@@ -9,6 +9,7 @@
 // [n][TC+1] (lanes run along columns -> conflict-free butterflies); log2(n) in-place stages (a,b)->(a+b,a-b) in the
 // same order as the oracle, scaled by 1/sqrt(n) on the way out.  HBM-bound (one read + one write of the weight).
 #include "nq_common.h"
+#include "quant_elem.h"
 
 namespace {
 
@@ -21,6 +22,7 @@ namespace {
 #define NQ_FWHT_TPB 512
 #endif
 constexpr int TPB = NQ_FWHT_TPB;
+constexpr int FW_MAXSEG_FQ = 16;
 #ifndef NQ_FWHT_TILE
 #define NQ_FWHT_TILE 8192
 #endif
@@ -125,6 +127,217 @@ __device__ __forceinline__ void fwht_block(float* lds, int blk, const float* __r
         c -= n_out;
         ++ol;
       }
+    }
+  }
+}
+
+// ---- round 4: the AdaRound fake-quant / its backward + Adam fused with the transform (NeRV-3M + Hadamard spends a sixth of an
+//      iteration on the parameter side: fake-quant 15 us -> FWHT 17 us forward, FWHT 18 us -> d(alpha)+Adam 33 us backward; the
+//      transform-domain tensors are 1.75x the weights, and each of them crossed HBM twice between the two launches) ----
+// One tensor of a fused launch.  n > 0: a transformed weight, tiles of OPB outer rows as fwht_block; n == 0: a plain tensor
+// (the biases: no transform), blocks of TPB * 4 elements.
+struct FqSeg {
+  const float* x;       // transform-domain FP weight (outer, n, inner) / bias
+  float* alpha;         // rounding variables, same shape (const in the forward launch)
+  const float* delta;   // per outer row (per_row) or one scalar
+  const float* zp;
+  float* m;             // Adam moments (backward launch)
+  float* v;
+  const float* gy;      // backward: d(loss)/d(W^) (outer, c_in, inner) / d(loss)/d(b^)
+  float* y;             // forward: W^ (outer, c_in, inner) / b^
+  int64_t outer;
+  int n, log2n, inner, c_in, OPB, per_row, soft;
+  float sqrt_n, qmax, reg_weight;
+};
+struct FqMulti {
+  FqSeg s[FW_MAXSEG_FQ];
+  int blk0[FW_MAXSEG_FQ + 1];
+  int nseg;
+};
+
+// forward: y = H(Q(x))[:, :c_in]  (quant_layer.py:70-71 with AdaRoundQuantizer.forward, quantizer.py:288-300)
+__device__ __forceinline__ void fq_fwht_tile(float* lds, int blk, const FqSeg& g) {
+  const int n = g.n, inner = g.inner, OPB = g.OPB;
+  const int64_t o0 = (int64_t)blk * OPB;
+  const int nob = (int)min((int64_t)OPB, g.outer - o0);
+  const int TC = OPB * inner, LD = TC + 1;
+  const int d_c = TPB / inner, d_i = TPB - d_c * inner;
+  {
+    const int per_o = n * inner, total = nob * per_o;
+    const float* __restrict__ xb = g.x + o0 * per_o;
+    const float* __restrict__ ab = g.alpha + o0 * per_o;
+    int ol = threadIdx.x / per_o, r = threadIdx.x - ol * per_o;
+    int c = r / inner, ii = r - c * inner;
+    for (int e = threadIdx.x; e < OPB * per_o; e += TPB) {
+      float q = 0.f;
+      if (e < total) {
+        const int64_t row = g.per_row ? o0 + ol : 0;
+        float xq;
+        q = ada_fwd_elem(xb[e], ab[e], g.delta[row], g.zp[row], g.qmax, g.soft, xq);
+      }
+      lds[c * LD + ol * inner + ii] = q;
+      ii += d_i;
+      c += d_c;
+      if (ii >= inner) {
+        ii -= inner;
+        ++c;
+      }
+      while (c >= n) {
+        c -= n;
+        ++ol;
+      }
+    }
+  }
+  __syncthreads();
+  fwht_stages(lds, n, g.log2n, TC, LD);
+  {
+    const int n_out = g.c_in;
+    const int per_o = n_out * inner, total = nob * per_o;
+    float* __restrict__ yb = g.y + o0 * per_o;
+    const bool pow2 = (g.log2n & 1) == 0;
+    const float inv = 1.0f / g.sqrt_n;
+    int ol = threadIdx.x / per_o, r = threadIdx.x - ol * per_o;
+    int c = r / inner, ii = r - c * inner;
+    for (int e = threadIdx.x; e < total; e += TPB) {
+      const float v = lds[c * LD + ol * inner + ii];
+      yb[e] = pow2 ? v * inv : v / g.sqrt_n;
+      ii += d_i;
+      c += d_c;
+      if (ii >= inner) {
+        ii -= inner;
+        ++c;
+      }
+      while (c >= n_out) {
+        c -= n_out;
+        ++ol;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void adaround_fwht_multi_kernel(FqMulti t) {
+  __shared__ float lds[LDS_FLOATS];
+  int k = 0;
+  while (k + 1 < t.nseg && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
+  const FqSeg& g = t.s[k];
+  const int blk = (int)blockIdx.x - t.blk0[k];
+  if (g.n > 0) {
+    fq_fwht_tile(lds, blk, g);
+    return;
+  }
+  const int64_t total = g.outer;   // plain tensor: outer = element count
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = (int64_t)blk * (TPB * 4) + u * TPB + threadIdx.x;
+    if (i < total) {
+      float xq;
+      g.y[i] = ada_fwd_elem(g.x[i], g.alpha[i], g.delta[0], g.zp[0], g.qmax, g.soft, xq);
+    }
+  }
+}
+
+// backward: g_T = H(pad(gy)) (the transform is its own transpose), then d(alpha) = ada_bwd_elem(x, g_T, alpha, ...) (+ the
+// regulariser's gradient) and Adam's update of alpha -- the arithmetic of adaround_adam_multi_kernel (quant.hip) element by
+// element, so alpha / m / v come out bit-identical to nq_fwht_multi + nq_adaround_adam_multi.
+__device__ __forceinline__ void fwht_ada_adam_tile(float* lds, int blk, const FqSeg& g, float reg_b, float rw, float step_size,
+                                                   float beta1, float beta2, float eps, float bc2_sqrt) {
+  const int n = g.n, inner = g.inner, OPB = g.OPB, n_in = g.c_in;
+  const int64_t o0 = (int64_t)blk * OPB;
+  const int nob = (int)min((int64_t)OPB, g.outer - o0);
+  const int TC = OPB * inner, LD = TC + 1;
+  for (int e = threadIdx.x; e < (n - n_in) * TC; e += TPB) {
+    const int c = n_in + e / TC, tt = e - (e / TC) * TC;
+    lds[c * LD + tt] = 0.f;
+  }
+  const int d_c = TPB / inner, d_i = TPB - d_c * inner;
+  {
+    const int per_o = n_in * inner, total = nob * per_o;
+    const float* __restrict__ xb = g.gy + o0 * per_o;
+    int ol = threadIdx.x / per_o, r = threadIdx.x - ol * per_o;
+    int c = r / inner, ii = r - c * inner;
+    for (int e = threadIdx.x; e < OPB * per_o; e += TPB) {
+      lds[c * LD + ol * inner + ii] = (e < total) ? xb[e] : 0.f;
+      ii += d_i;
+      c += d_c;
+      if (ii >= inner) {
+        ii -= inner;
+        ++c;
+      }
+      while (c >= n_in) {
+        c -= n_in;
+        ++ol;
+      }
+    }
+  }
+  __syncthreads();
+  fwht_stages(lds, n, g.log2n, TC, LD);
+  {
+    const int per_o = n * inner, total = nob * per_o;
+    const int64_t base = o0 * per_o;
+    const bool pow2 = (g.log2n & 1) == 0;
+    const float inv = 1.0f / g.sqrt_n;
+    int ol = threadIdx.x / per_o, r = threadIdx.x - ol * per_o;
+    int c = r / inner, ii = r - c * inner;
+    for (int e = threadIdx.x; e < total; e += TPB) {
+      const float t = lds[c * LD + ol * inner + ii];
+      const float gv = pow2 ? t * inv : t / g.sqrt_n;          // what nq_fwht stores
+      const int64_t i = base + e;
+      const int64_t row = g.per_row ? o0 + ol : 0;
+      const float gr = ada_bwd_elem(g.x[i], gv, g.alpha[i], g.delta[row], g.zp[row], g.qmax, rw, reg_b);
+      float mi = g.m[i], vi = g.v[i];
+      mi = mi + (1.f - beta1) * (gr - mi);
+      vi = vi * beta2 + (1.f - beta2) * (gr * gr);
+      const float denom = sqrtf(vi) / bc2_sqrt + eps;
+      g.m[i] = mi;
+      g.v[i] = vi;
+      g.alpha[i] = g.alpha[i] - step_size * (mi / denom);
+      ii += d_i;
+      c += d_c;
+      if (ii >= inner) {
+        ii -= inner;
+        ++c;
+      }
+      while (c >= n) {
+        c -= n;
+        ++ol;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void fwht_adaround_adam_multi_kernel(FqMulti t, float reg_b, float step_size, float beta1,
+                                                                       float beta2, float eps, float bc2_sqrt,
+                                                                       const float* __restrict__ dyn) {
+  __shared__ float lds[LDS_FLOATS];
+  float gate = 1.f;
+  if (dyn) {   // per-step scalars from device memory (graph replays): {reg_b, regulariser gate, lr/(1-beta1^t), sqrt(1-beta2^t)}
+    reg_b = dyn[0];
+    gate = dyn[1];
+    step_size = dyn[2];
+    bc2_sqrt = dyn[3];
+  }
+  int k = 0;
+  while (k + 1 < t.nseg && (int)blockIdx.x >= t.blk0[k + 1]) ++k;
+  const FqSeg& g = t.s[k];
+  const int blk = (int)blockIdx.x - t.blk0[k];
+  const float rw = dyn ? g.reg_weight * gate : g.reg_weight;   // gate is exactly 0 or 1
+  if (g.n > 0) {
+    fwht_ada_adam_tile(lds, blk, g, reg_b, rw, step_size, beta1, beta2, eps, bc2_sqrt);
+    return;
+  }
+  const int64_t total = g.outer;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int64_t i = (int64_t)blk * (TPB * 4) + u * TPB + threadIdx.x;
+    if (i < total) {
+      const float gr = ada_bwd_elem(g.x[i], g.gy[i], g.alpha[i], g.delta[0], g.zp[0], g.qmax, rw, reg_b);
+      float mi = g.m[i], vi = g.v[i];
+      mi = mi + (1.f - beta1) * (gr - mi);
+      vi = vi * beta2 + (1.f - beta2) * (gr * gr);
+      const float denom = sqrtf(vi) / bc2_sqrt + eps;
+      g.m[i] = mi;
+      g.v[i] = vi;
+      g.alpha[i] = g.alpha[i] - step_size * (mi / denom);
     }
   }
 }
@@ -256,5 +469,71 @@ extern "C" int nq_fwht_multi(const nq_fwht_seg* segs, int nseg, nq_stream_t stre
     ++t.nseg;
   }
   flush();
+  return nq_launch_status();
+}
+
+// One tensor of the fused launches (include/nq_hip.h: nq_fq_fwht_seg) -> device segment; 0 on success
+static int fq_fill(FqSeg& d, const nq_fq_fwht_seg& h, bool bwd, int* blocks) {
+  if (!h.x || !h.alpha || !h.delta || !h.zp || h.outer <= 0 || h.inner <= 0 || h.n_levels < 2) return NQ_ERR_INVALID;
+  if (bwd ? (!h.gy || !h.m || !h.v) : !h.y) return NQ_ERR_INVALID;
+  d.x = h.x; d.alpha = h.alpha; d.delta = h.delta; d.zp = h.zp; d.m = h.m; d.v = h.v; d.gy = h.gy; d.y = h.y;
+  d.per_row = h.per_row; d.soft = h.soft; d.qmax = (float)(h.n_levels - 1); d.reg_weight = h.reg_weight;
+  if (h.n == 0) {   // plain tensor (a bias): no transform
+    d.n = 0; d.log2n = 0; d.inner = 1; d.c_in = 0; d.OPB = 0; d.sqrt_n = 1.f;
+    d.outer = h.outer * h.inner;
+    if (d.per_row) return NQ_ERR_UNSUPPORTED;
+    *blocks = (int)((d.outer + TPB * 4 - 1) / (TPB * 4));
+    return NQ_OK;
+  }
+  if (h.n < 0 || (h.n & (h.n - 1)) != 0 || h.c_in <= 0 || h.c_in > h.n) return NQ_ERR_INVALID;
+  if (h.n > 1024 || (int64_t)h.n * h.inner > TILE) return NQ_ERR_UNSUPPORTED;   // (longer rows: the unfused launches)
+  int log2n = 0;
+  while ((1 << log2n) < h.n) ++log2n;
+  int OPB = (int)(TILE / ((int64_t)h.n * h.inner));
+  const int cap = (int)((NQ_FWHT_COLS + h.inner - 1) / h.inner);
+  if (OPB > cap) OPB = cap;
+  if (OPB < 1) OPB = 1;
+  d.outer = h.outer; d.n = h.n; d.log2n = log2n; d.inner = (int)h.inner; d.c_in = h.c_in; d.OPB = OPB; d.sqrt_n = sqrtf((float)h.n);
+  const int64_t nb = (h.outer + OPB - 1) / OPB;
+  if (nb > 0x3fffffffLL) return NQ_ERR_UNSUPPORTED;
+  *blocks = (int)nb;
+  return NQ_OK;
+}
+
+extern "C" int nq_adaround_fwht_multi(const nq_fq_fwht_seg* segs, int nseg, nq_stream_t stream) {
+  if (!segs || nseg <= 0) return NQ_ERR_INVALID;
+  for (int base = 0; base < nseg; base += FW_MAXSEG_FQ) {
+    FqMulti t;
+    t.nseg = (nseg - base < FW_MAXSEG_FQ) ? nseg - base : FW_MAXSEG_FQ;
+    int blocks = 0;
+    for (int i = 0; i < t.nseg; ++i) {
+      int nb = 0;
+      if (int rc = fq_fill(t.s[i], segs[base + i], false, &nb)) return rc;
+      t.blk0[i] = blocks;
+      blocks += nb;
+    }
+    t.blk0[t.nseg] = blocks;
+    hipLaunchKernelGGL(adaround_fwht_multi_kernel, dim3((unsigned)blocks), dim3(TPB), 0, nq_s(stream), t);
+  }
+  return nq_launch_status();
+}
+
+extern "C" int nq_fwht_adaround_adam_multi(const nq_fq_fwht_seg* segs, int nseg, float reg_b, float step_size, float beta1,
+                                           float beta2, float eps, float bc2_sqrt, const float* dyn, nq_stream_t stream) {
+  if (!segs || nseg <= 0) return NQ_ERR_INVALID;
+  for (int base = 0; base < nseg; base += FW_MAXSEG_FQ) {
+    FqMulti t;
+    t.nseg = (nseg - base < FW_MAXSEG_FQ) ? nseg - base : FW_MAXSEG_FQ;
+    int blocks = 0;
+    for (int i = 0; i < t.nseg; ++i) {
+      int nb = 0;
+      if (int rc = fq_fill(t.s[i], segs[base + i], true, &nb)) return rc;
+      t.blk0[i] = blocks;
+      blocks += nb;
+    }
+    t.blk0[t.nseg] = blocks;
+    hipLaunchKernelGGL(fwht_adaround_adam_multi_kernel, dim3((unsigned)blocks), dim3(TPB), 0, nq_s(stream), t, reg_b, step_size,
+                       beta1, beta2, eps, bc2_sqrt, dyn);
+  }
   return nq_launch_status();
 }

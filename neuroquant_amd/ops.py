@@ -426,6 +426,71 @@ def fwht_channels_multi(items):
     return outs
 
 
+def _fq_fwht_segs(items, bwd):
+    """items: [(x, alpha, delta, zp, n_levels, soft, n, c_in, reg_weight, gy, m, v)] -> (FqFwhtSeg array, outputs, keep-alive).
+    n == 0: a plain tensor (bias); else x / alpha are (C_out, n, kh, kw) and the spatial side is (C_out, c_in, kh, kw)."""
+    segs = (L.FqFwhtSeg * len(items))()
+    outs, keep = [], []
+    for sg, (x, alpha, delta, zp, n_levels, soft, n, c_in, reg_weight, gy, m, v) in zip(segs, items):
+        x, alpha, delta, zp = _dev(x), _dev(alpha), _dev(delta), _dev(zp)
+        sg.x, sg.alpha, sg.delta, sg.zp = _p(x), _p(alpha), _p(delta), _p(zp)
+        sg.n_levels, sg.soft, sg.reg_weight = n_levels, int(bool(soft)), float(reg_weight)
+        if n:
+            co, npad, kh, kw = x.shape
+            if npad != n or delta.numel() not in (1, co):
+                raise RuntimeError("fused fake-quant + FWHT: x must be (C_out, n, kh, kw) with per-channel or scalar delta")
+            sg.outer, sg.inner, sg.n, sg.c_in, sg.per_row = co, kh * kw, n, c_in, int(delta.numel() > 1)
+            spatial = (co, c_in, kh, kw)
+        else:
+            if delta.numel() != 1:
+                raise RuntimeError("fused fake-quant + FWHT: a plain tensor takes one scalar delta / zero point")
+            sg.outer, sg.inner, sg.n, sg.c_in, sg.per_row = x.numel(), 1, 0, 0, 0
+            spatial = tuple(x.shape)
+        if bwd:
+            gy = _dev(gy)
+            if tuple(gy.shape) != spatial:
+                raise RuntimeError(f"fused FWHT + d(alpha) + Adam: gradient shape {tuple(gy.shape)} != {spatial}")
+            sg.gy, sg.m, sg.v = _p(gy), _p(m), _p(v)
+            keep.append((x, gy))
+        else:
+            y = torch.empty(spatial, device=x.device, dtype=torch.float32)
+            sg.y = _p(y)
+            outs.append(y)
+            keep.append(x)
+    return segs, outs, keep
+
+
+def adaround_fwht_multi(items):
+    """items: [(x, alpha, delta, zp, n_levels, soft, n, c_in)] -> [H(Q(x))[:, :c_in]] (n == 0: Q(x) of a bias), ONE launch
+    (nq_adaround_fwht_multi): bit-identical to adaround_forward_multi followed by fwht_channels_multi."""
+    segs, outs, keep = _fq_fwht_segs([it + (0.0, None, None, None) for it in items], bwd=False)
+    L.check(L.lib().nq_adaround_fwht_multi(segs, len(items), _stream()), "adaround_fwht_multi")
+    return outs
+
+
+def fwht_adaround_adam_multi(items, opt, reg_b=0.0, dyn=None, beta1=0.9, beta2=0.999, eps=1e-8):
+    """items: [(x, gy, alpha, delta, zp, n_levels, reg_weight, n, c_in)] in the order of opt.params (= the alphas); gy is the
+    SPATIAL-domain gradient d(loss)/d(W^) (C_out, c_in, kh, kw) (n == 0: the bias gradient).  H on the zero-padded gradient,
+    d(alpha) (+ regulariser gradient) and opt's Adam step in ONE launch; advances opt.t.  Bit-identical to
+    fwht_channels_multi + adaround_adam_multi."""
+    assert len(items) == len(opt.params)
+    opt.t += 1
+    full = []
+    for i, (x, gy, alpha, delta, zp, n_levels, reg_weight, n, c_in) in enumerate(items):
+        if alpha.data_ptr() != opt.params[i].data_ptr():
+            raise RuntimeError("fwht_adaround_adam_multi: items must be in the optimiser's parameter order")
+        full.append((x, alpha, delta, zp, n_levels, True, n, c_in, reg_weight, gy, opt.m[i], opt.v[i]))
+    segs, _, keep = _fq_fwht_segs(full, bwd=True)
+    step_size, bc2_sqrt = opt.scalars(opt.t, beta1, beta2)
+    L.check(L.lib().nq_fwht_adaround_adam_multi(segs, len(items), float(reg_b), step_size, beta1, beta2, eps, bc2_sqrt, _p(dyn),
+                                                _stream()), "fwht_adaround_adam_multi")
+
+
+def fq_fwht_fusable(n, inner):
+    """rows short enough for the fused launches' LDS tile (every layer of the shipped models: n <= 256, 3 x 3 kernels)"""
+    return n * inner <= 8192 and n <= 1024
+
+
 class _HadamardFn(Function):
     @staticmethod
     def forward(ctx, w, n, n_out):

@@ -285,6 +285,11 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
             fin()
         graphs[-1].replay()
 
+    # Hadamard runs: the fake-quant and the transform share one launch per direction (round 4) when every layer's rows fit the
+    # fused kernels' tile (all shipped models); NQ_FUSED_FWHT=0 keeps the separate launches (bit-identical either way, tested)
+    fuse_had = bool(hadamard) and os.environ.get("NQ_FUSED_FWHT", "1") != "0" and \
+        all(ops.fq_fwht_fusable(L.n, L.src.shape[2] * L.src.shape[3]) for L in layers)
+
     def run(epochs, params, opt_lr, max_count, ada):
         nonlocal done
         opt = ops.FusedAdam(params, lr=opt_lr)
@@ -304,7 +309,15 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
             staged(k, part): data-parallel captured iterations -- the decoder runs without autograd and `staged` is called
             with every complete part of the gradient arena (k = 0, 1), where the caller cuts the graph / reduces the part."""
             img, inputs = get_batch()
-            if ada:   # all 14 fake-quantised tensors in one launch
+            if ada and fuse_had:   # fake-quant + H of all layers (and the fake-quant of the biases) in ONE launch
+                items = []
+                for L in layers:
+                    (xw, aw, dw_, zw, nlw, sw), (xb, ab, db_, zb, nlb, sb) = L.ada_items()
+                    items += [(xw, aw, dw_, zw, nlw, sw, L.n, L.c_in), (xb, ab, db_, zb, nlb, sb, 0, 0)]
+                fq = ops.adaround_fwht_multi(items)
+                for i, L in enumerate(layers):
+                    L._finish(fq[2 * i], fq[2 * i + 1], transformed=True)
+            elif ada:   # all 14 fake-quantised tensors in one launch
                 fq = ops.adaround_forward_multi(
                     [it for L in layers for it in L.ada_items()])
                 if hadamard:   # H(Q(H w)) of every layer in one launch (quant_layer.py:70-71)
@@ -374,7 +387,18 @@ def model_reconstruction(model: QuantModel, cali_data: torch.Tensor, gt, arch: s
                     logging.info('Total loss:\t{:.4f} (rec:{:.4f}, round:{:.4f})\tb={:.2f}\tcount={}'.format(
                         total, float(rec), rl_f, b, count))
             grads = []
-            if ada:   # d(alpha) of all 14 tensors (+ regulariser gradient on the weights) in one launch
+            if ada and fuse_had and probe is None and os.environ.get("NQ_FUSED_ADAM", "1") != "0":
+                # H on the zero-padded gradients + d(alpha) + regulariser gradient + Adam of all layers in ONE launch: the
+                # transform-domain gradient never goes to memory
+                items = []
+                for L in layers:
+                    wq, bq = L.m.weight_quantizer, L.m.bias_quantizer
+                    items.append((L.src, L.W.grad, wq.alpha.data, wq.delta.data, wq.zero_point, wq.n_levels,
+                                  weight if (reg_on or dyn is not None) else 0.0, L.n, L.c_in))
+                    items.append((L.bias, L.b.grad, bq.alpha.data, bq.delta.data, bq.zero_point, bq.n_levels, 0.0, 0, 0))
+                ops.fwht_adaround_adam_multi(items, opt, b, dyn=dyn)
+                grads = None
+            elif ada:   # d(alpha) of all 14 tensors (+ regulariser gradient on the weights) in one launch
                 items = []
                 # H on the zero-padded gradients of all layers in one launch
                 gWs = ops.fwht_channels_multi([(L.W.grad, L.n, L.n) for L in layers]) if hadamard else None

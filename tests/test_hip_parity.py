@@ -1202,6 +1202,59 @@ def test_fused_adaround_backward_adam_is_bit_identical(ops, use_dyn):
     assert not torch.equal(a_par[0], make()[1][0])      # the parameters did move
 
 
+@pytest.mark.parametrize("use_dyn", [False, True])
+def test_fused_fakequant_fwht_launches_are_bit_identical(ops, use_dyn):
+    """Round 4: the launches that fuse the AdaRound fake-quant with the Hadamard transform (nq_adaround_fwht_multi forward,
+    nq_fwht_adaround_adam_multi backward + Adam) against the launches they replace (adaround_forward_multi + fwht_channels_multi,
+    fwht_channels_multi + adaround_adam_multi): W^, alpha, m, v bit for bit, over NeRV-3M's transform lengths (256 ... 32), a
+    1 x 1 and a 5 x 5 kernel, ragged last tiles, and the biases as plain segments."""
+    g = torch.Generator().manual_seed(77)
+    shapes = [(50, 145, 3), (37, 72, 3), (9, 24, 3), (21, 160, 1), (7, 20, 5), (3, 24, 3)]   # (C_out, C_in, k)
+    tens = []
+    for co, ci, k in shapes:
+        n = ops.next_pow2(ci)
+        x = torch.randn(co, n, k, k, generator=g).to(DEV)
+        delta = (torch.rand(co, 1, 1, 1, generator=g) * 0.05 + 0.01).to(DEV)
+        zp = torch.randint(3, 12, (co, 1, 1, 1), generator=g).float().to(DEV)
+        bias = torch.randn(co, generator=g).to(DEV)
+        bdelta, bzp = torch.tensor([0.07]).to(DEV), torch.tensor([6.0]).to(DEV)
+        tens.append(dict(x=x, n=n, ci=ci, delta=delta, zp=zp, bias=bias, bdelta=bdelta, bzp=bzp,
+                         alpha=torch.randn(co, n, k, k, generator=g).to(DEV) * 2, balpha=torch.randn(co, generator=g).to(DEV),
+                         gy=torch.randn(co, ci, k, k, generator=g).to(DEV), gb=torch.randn(co, generator=g).to(DEV)))
+    nl = 16
+    # ---- forward ----
+    fq = ops.adaround_forward_multi([it for t in tens for it in ((t["x"], t["alpha"], t["delta"], t["zp"], nl, True),
+                                                                   (t["bias"], t["balpha"], t["bdelta"], t["bzp"], nl, True))])
+    want_w = ops.fwht_channels_multi([(fq[2 * i], t["n"], t["ci"]) for i, t in enumerate(tens)])
+    got = ops.adaround_fwht_multi([it for t in tens for it in ((t["x"], t["alpha"], t["delta"], t["zp"], nl, True, t["n"], t["ci"]),
+                                                                (t["bias"], t["balpha"], t["bdelta"], t["bzp"], nl, True, 0, 0))])
+    for i, t in enumerate(tens):
+        assert got[2 * i].shape == want_w[i].shape and torch.equal(got[2 * i], want_w[i]), i
+        assert torch.equal(got[2 * i + 1], fq[2 * i + 1]), i
+    # ---- backward + Adam, two steps (the second on moved alphas and non-zero moments) ----
+    def params():
+        return [p.clone() for t in tens for p in (t["alpha"], t["balpha"])]
+    pa, pb = params(), params()
+    oa, ob = ops.FusedAdam(pa, lr=3e-3), ops.FusedAdam(pb, lr=3e-3)
+    for step in range(2):
+        rb, rw = 20.0 - 3 * step, 0.01
+        dyn = None
+        if use_dyn:
+            dyn = torch.tensor([rb, 1.0, *oa.scalars(oa.t + 1)], dtype=torch.float32).to(DEV)
+        gT = ops.fwht_channels_multi([(t["gy"], t["n"], t["n"]) for t in tens])
+        items_a, items_b = [], []
+        for i, t in enumerate(tens):
+            items_a += [(t["x"], gT[i], pa[2 * i], t["delta"], t["zp"], nl, rw), (t["bias"], t["gb"], pa[2 * i + 1], t["bdelta"], t["bzp"], nl, 0.0)]
+            items_b += [(t["x"], t["gy"], pb[2 * i], t["delta"], t["zp"], nl, rw, t["n"], t["ci"]),
+                        (t["bias"], t["gb"], pb[2 * i + 1], t["bdelta"], t["bzp"], nl, 0.0, 0, 0)]
+        ops.adaround_adam_multi(items_a, oa, rb, dyn=dyn)
+        ops.fwht_adaround_adam_multi(items_b, ob, rb, dyn=dyn)
+        for j, (a_, b_) in enumerate(zip(pa, pb)):
+            assert torch.equal(a_, b_), (step, j)
+            assert torch.equal(oa.m[j], ob.m[j]) and torch.equal(oa.v[j], ob.v[j]), (step, j)
+        assert float((pa[0] - tens[0]["alpha"]).abs().max()) > 0
+
+
 def test_uaq_multi_tensor_launches_are_bit_identical(ops):
     """nq_uaq_forward_multi / nq_uaq_backward_multi (round 3: phase 1 in two launches instead of 28) against the
     single-tensor entry points: per-row and scalar scales, 4-D weights and 1-D biases, ragged sizes."""
