@@ -352,14 +352,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_multi_kernel(WGRMulti t) {
     n = 4 * (int)(i - (int64_t)co * NQ);
     const float* p = q.slab + (int64_t)co * q.n_pad + n;
     const int64_t stride = (int64_t)q.co_pad * q.n_pad;
-#pragma unroll 4
+#pragma unroll 8
     for (int j = g; j < nsplit; j += SG) {
       const float4 v = *reinterpret_cast<const float4*>(p + j * stride);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
   } else if (q.db && i < total + Cout) {
     const int cb = (int)(i - total);
-#pragma unroll 4
+#pragma unroll 8
     for (int j = g; j < nsplit; j += SG) s.x += q.slab_db[(int64_t)j * q.co_pad + cb];
   }
   if (SG > 1) {   // block-uniform

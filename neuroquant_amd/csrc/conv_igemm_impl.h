@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(ConvArgs a) {
   int64_t i = (int64_t)blockIdx.x * OG + o;
   float v = 0.f;
   if (i < total) {
-#pragma unroll 4
+#pragma unroll 8
     for (int s = g; s < a.nsplit; s += SG) v += a.slab[s * total + i];
   }
   if (SG > 1) {

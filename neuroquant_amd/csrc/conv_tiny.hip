@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void tiny_pw_fwd_kernel(const float* __restric
   const int b = bp / HW, p = bp - b * HW;
   const float* __restrict__ xp = x + (int64_t)b * Cin * HW + p;
   float acc = 0.f;
-#pragma unroll 4
+#pragma unroll 8
   for (int ci = ks; ci < Cin; ci += KSL) acc = fmaf(wt[(int64_t)ci * ld + co], xp[(int64_t)ci * HW], acc);
   if (KSL > 1) {
     part[ks][o] = acc;
@@ -80,7 +80,18 @@ __global__ __launch_bounds__(256) void tiny_pw_wgrad_kernel(const float* __restr
     for (int b = 0; b < B; ++b) {
       const float* __restrict__ dp = dy + ((int64_t)b * Cout + co) * HW;
       const float* __restrict__ xp = x + ((int64_t)b * Cin + ci) * HW;
-      for (int p = 0; p < HW; ++p) acc = fmaf(dp[p], xp[p], acc);
+      if ((HW & 7) == 0) {
+        // eight pixels per step, their four 16-byte loads in flight together (the scalar loop waited for two L2 round trips
+        // per multiply-add: 8.8 us for HNeRV's dec1); the additions keep the pixel order
+        for (int p = 0; p < HW; p += 8) {
+          const float4 d0 = *reinterpret_cast<const float4*>(dp + p), d1 = *reinterpret_cast<const float4*>(dp + p + 4);
+          const float4 x0 = *reinterpret_cast<const float4*>(xp + p), x1 = *reinterpret_cast<const float4*>(xp + p + 4);
+          acc = fmaf(d0.x, x0.x, acc); acc = fmaf(d0.y, x0.y, acc); acc = fmaf(d0.z, x0.z, acc); acc = fmaf(d0.w, x0.w, acc);
+          acc = fmaf(d1.x, x1.x, acc); acc = fmaf(d1.y, x1.y, acc); acc = fmaf(d1.z, x1.z, acc); acc = fmaf(d1.w, x1.w, acc);
+        }
+      } else {
+        for (int p = 0; p < HW; ++p) acc = fmaf(dp[p], xp[p], acc);
+      }
     }
     dw[t] = acc;
   } else if (db && t < nw + Cout) {
