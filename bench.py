@@ -172,6 +172,9 @@ def main():
                     "checkpoint and the real Bunny crops)")
     ap.add_argument("--no-uvg", action="store_true", help="skip the `uvg` object (BASELINE configs[4] shape + Omega sweep timing)")
     ap.add_argument("--uvg-steps", type=int, default=10)
+    ap.add_argument("--precision", choices=("bf16x3", "fp32"), default="bf16x3",
+                    help="convolution precision of the HEADLINE runs (default bf16x3; fp32 = exact fp32-input MFMA: used to "
+                         "profile that path -- the default line already carries it as the `fp32` object)")
     ap.add_argument("--workload", choices=("hnerv", "nerv", "uvg12m"), default="hnerv",
                     help="hnerv = the headline config (default); nerv = NeRV-3M + Hadamard (BASELINE configs[2]); uvg12m = HNeRV UVG "
                          "960x1920 ~12M (BASELINE configs[4] shape) as the headline line of this run; neither has a cpu baseline")
@@ -324,10 +327,10 @@ def main():
                     prof_steps=prof_steps)
 
     nerv = args.workload == "nerv"
-    main_run = timed_run("bf16x3", K, W)
+    main_run = timed_run(args.precision, K, W)
     # the same K timed steps again (fresh model, same warm-up): the spread the 47 ms timed region has on this box goes into
     # the line (`repeats`); `value` stays the first, contract run
-    more_runs = [timed_run("bf16x3", K, W) for _ in range(max(args.repeats - 1, 0))]
+    more_runs = [timed_run(args.precision, K, W) for _ in range(max(args.repeats - 1, 0))]
     # the secondary objects (exact fp32, phase 1, NeRV) describe the single-GPU kernels: N = 1 only -- at N > 1 the line is
     # the data-parallel headline and its repeats, nothing else rides on the collectives
     if world > 1:
@@ -364,7 +367,7 @@ def main():
         print(json.dumps({"value": round(K * per_step_units / elapsed, 3), "ms_per_step": round(elapsed / K * 1e3, 3),
                           "note": "no profiling"}))
         return
-    roofline, rows = roofline_of(main_run["prof"], elapsed, K, main_run["t_enq"], "bf16x3", main_run["prof_steps"])
+    roofline, rows = roofline_of(main_run["prof"], elapsed, K, main_run["t_enq"], args.precision, main_run["prof_steps"])
     try:  # per-kernel table for DESIGN.md / profiles (scratch; not part of the contract line)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", f"bench_kernels_n{world}.json"), "w") as f:
@@ -454,7 +457,8 @@ def main():
                  else "it/s (B=2 frames per iteration-equivalent, summed over GPUs)"),
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 3),
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-        "dtype": "f32 operands split into bf16 hi+lo, 3 BF16 MFMAs per product, fp32 accumulate (bf16x3); fp32 MFMA on small layers",
+        "dtype": ("f32 operands split into bf16 hi+lo, 3 BF16 MFMAs per product, fp32 accumulate (bf16x3); fp32 MFMA on small layers"
+                  if args.precision == "bf16x3" else "f32 (exact fp32-input MFMA, --precision fp32)"),
         "data": "synthetic",
         "config": {"workload": {"nerv": "NeRV Bunny_1280x640_3M + Hadamard", "hnerv": "HNeRV Bunny_1280x640_3M",
                                 "uvg12m": "HNeRV UVG 960x1920 ~12M (tools/hnerv_uvg_12m.yaml)"}[args.workload]

@@ -4,13 +4,14 @@
 # summaries go to profiles/<tag>_* via profiles/summarize.py.  Output is kept under gpurun_out/ (merged back by gpurun).
 set -e
 TAG=${1:-rXX}
-WL=${2:-hnerv}          # hnerv (the headline workload) | nerv (BASELINE configs[2]: NeRV-3M + Hadamard)
+WL=${2:-hnerv}          # hnerv (the headline workload) | nerv (BASELINE configs[2]: NeRV-3M + Hadamard) | uvg12m (configs[4] shape)
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 MODE=${3:-full}         # full | trace (only the per-iteration kernel sequence: one short run)
-BENCH="python3 $R/bench.py --frames 8 --workload $WL --no-cpu-baseline --no-fp32 --no-nerv --no-phase1 --no-trained --no-uvg --repeats 1"
+PREC=${4:-bf16x3}       # bf16x3 | fp32 (exact fp32-input MFMA convolutions)
+BENCH="python3 $R/bench.py --frames 8 --workload $WL --precision $PREC --no-cpu-baseline --no-fp32 --no-nerv --no-phase1 --no-trained --no-uvg --repeats 1"
 if [ "$MODE" = "trace" ]; then
   rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- $BENCH --steps 12 --warmup 5 > $OUT/trace.log 2>&1
   cd $R
