@@ -149,11 +149,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   // (1 KiB each: wave-uniform LDS base + lane * 16), no registers, no ds_write, and a prefetch distance of THREE k-steps
   // into a ring of four buffers at no register cost.  Every wave issues exactly WPT pieces per k-step, so that the counted
   // waits below are the same for all waves: the pieces past W_U4 in the last round (W_U4 is a multiple of 128 units, a
-  // piece is 64: whole pieces) land in a dump area behind the ring (their source is unit 0: valid memory).
+  // piece is 64: whole pieces) REPEAT the wave's first piece -- same source, same destination, the same bytes written twice
+  // (round 4; a 2 KB dump area behind the ring before: without it the 48-channel tile of a 5 x 5 layer is 52.2 KB, three
+  // workgroups per CU fit).
   constexpr int WS = W_U4;                     // buffer stride in 16-byte units
   constexpr int WDUMP = WPT * 256 - W_U4;      // units of the dump area (0 for the 32- and 64-channel tiles)
   u32x4* const wl0 = smem + PATCH_U4;          // weight buffers: k-step g lives in buffer g & WMASK
-  u32x4* const wdump = wl0 + NB * W_U4;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l16 = lane & 15, kq = lane >> 4;
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     u32x4* const d_ = wl0 + ((G) & (NB - 1)) * WS + wave_u * 64;                                             \
     _Pragma("unroll") for (int i = 0; i < WPT; ++i) {                                                 \
       if (WDUMP == 0 || i + 1 < WPT) NQ3_DMA_PIECE(d_ + i * 256, wvo[i], so_)                         \
-      else NQ3_DMA_PIECE((i * 256 + wave_u * 64 < W_U4) ? d_ + i * 256 : wdump + (i * 256 + wave_u * 64 - W_U4), wvo[i], so_) \
+      else NQ3_DMA_PIECE((i * 256 + wave_u * 64 < W_U4) ? d_ + i * 256 : d_, wvo[i], so_) \
     }                                                                                                 \
   }
   // counted wait for this wave's LDS-DMA pieces: at most N VMEM operations still in flight
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   const int G = nfull * NST + (tail == 1 ? NST4 : (tail == 2 ? NST8 : (tail == 3 ? NST12 : 0)));
   const int Gm1 = G - 1;
   // per-thread byte offsets of its weight units within one k-step (fixed): unit f = tid + i*256 of [plane][kq][MT]; a
-  // thread without an item in the last round loads unit 0 (valid memory, never stored)
+  // thread without an item in the last round repeats its first unit (see WDUMP above)
   const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt3), 0, (int)a.w_bytes, 0x00020000);
   const unsigned w_step_bytes = (unsigned)(w_step_stride * 16);
   unsigned wvo[WPT];
@@ -310,8 +311,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
   for (int i = 0; i < WPT; ++i) {
     const int f_ = tid + i * 256;
     const bool ok_ = NQ_IG3_ABL != 5 && (i + 1 < WPT || f_ < W_U4);
-    const int pl_ = f_ / (4 * MT), rem_ = f_ - pl_ * (4 * MT);
-    wvo[i] = (unsigned)(cot * 4 * MT + (ok_ ? pl_ * (int)w_plane_stride + rem_ : 0)) * 16u;
+    const int fe_ = (ok_ || !WDMA) ? f_ : tid;   // (register-staged tiles: the value is never stored)
+    const int pl_ = fe_ / (4 * MT), rem_ = fe_ - pl_ * (4 * MT);
+    wvo[i] = (unsigned)(cot * 4 * MT + ((ok_ || WDMA) ? pl_ * (int)w_plane_stride + rem_ : 0)) * 16u;
   }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   if constexpr (WDMA) {   // steps 0..D-1 on their way before the patch loads (whose first use below waits for everything)
@@ -753,7 +755,7 @@ template <int MI>
 int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
   constexpr int MT = 16 * MI;
   size_t lds = (size_t)(PATCH_U4 + 2 * 2 * 4 * MT) * 16;   // patch + two weight buffers (register-staged tiles)
-  if (MI >= 3) lds = (size_t)(PATCH_U4 + 4 * (2 * 4 * MT) + ((2 * 4 * MT + 255) / 256 * 256 - 2 * 4 * MT)) * 16;  // DMA ring of 4 + dump area
+  if (MI >= 3) lds = (size_t)(PATCH_U4 + 4 * (2 * 4 * MT)) * 16;  // DMA ring of 4
   Conv3Args a = a_in;
   a.lds_epi = 0;
   if (a.epi == NQ_EPI_DGRAD_GELU && a.nsplit == 1 && MI <= 4) {   // 4 waves x [MT][64] floats for the wide epilogue
