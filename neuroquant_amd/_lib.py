@@ -71,6 +71,11 @@ def _load():
         raise NQLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C neuroquant_amd/csrc`).  neuroquant_amd has no CPU/eager fallback.")
+    # ONE HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 and libnqhip.so is linked against the system one
+    # (same SONAME).  Whichever is loaded first serves both -- so torch goes first: with the system runtime loaded first,
+    # torch later brings its own, this library's kernels are registered with the other one, and every launch fails
+    # (seen with __graft_entry__.build() followed by smoke() in one process).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     P, I, L, F = c_void_p, c_int, c_int64, c_float
 
