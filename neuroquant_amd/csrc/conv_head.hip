@@ -180,7 +180,7 @@ struct HeadLossArgs {
 
 // (the pointers are kernel PARAMETERS with __restrict__: the compiler then knows that the stores to y cannot change x / wt)
 // wt[(ci*9 + tap)*ld + co], zero for co >= CO (nq_weight_layouts)
-template <int R, int NCO, bool TANH, bool LOSS = false, int PD = 2>
+template <int R, int NCO, bool TANH, bool LOSS = false>
 __global__ __launch_bounds__(256) void head_fwd2_kernel(const float* __restrict__ x_, const float* __restrict__ wt,
                                                         const float* __restrict__ bias, float* __restrict__ y_,
                                                         HeadFwd2Args a, HeadLossArgs la = HeadLossArgs{}) {
@@ -273,35 +273,6 @@ __global__ __launch_bounds__(256) void head_fwd2_kernel(const float* __restrict_
   f32x4 vA[NR], vB[NR];
   float eA[NR], eB[NR];
   float4 wA[KK], wB[KK];
-  if constexpr (PD == 2) {
-    // Round 4: the activations TWO channels ahead (three register sets), the weights one (two SGPR sets: a third does not
-    // fit).  A channel's 216 v_pk_fma take ~0.4 us of a wave's time, its loads come back after ~2 us: with one channel in
-    // flight the wave spent 74 us / 37 channels = one memory round trip per channel (wait_any 0.33-0.44 at 1.6 waves per
-    // SIMD; rows per wave R = 2 ... 5 changed nothing).  Six channels per trip of the loop: x sets rotate mod 3, w sets mod 2;
-    // past the last channel the loads repeat it and the compute is skipped (wave-uniform).
-    f32x4 vC[NR];
-    float eC[NR];
-    load_x(0, vA, eA);
-    load_x(1, vB, eB);
-    load_w(0, wA);
-#define NQ_HF_STEP(C_, XC, EC, WC, XN, EN, WN)                              \
-    load_x((C_) + 2, XN, EN);                                              \
-    load_w((C_) + 1, WN);                                                  \
-    __builtin_amdgcn_sched_barrier(0);                                     \
-    if ((C_) < Cin) compute(XC, EC, WC);                                   \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                    \
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-    for (int ci = 0; ci < Cin; ci += 6) {
-      NQ_HF_STEP(ci, vA, eA, wA, vC, eC, wB)
-      NQ_HF_STEP(ci + 1, vB, eB, wB, vA, eA, wA)
-      NQ_HF_STEP(ci + 2, vC, eC, wA, vB, eB, wB)
-      NQ_HF_STEP(ci + 3, vA, eA, wB, vC, eC, wA)
-      NQ_HF_STEP(ci + 4, vB, eB, wA, vA, eA, wB)
-      NQ_HF_STEP(ci + 5, vC, eC, wB, vB, eB, wA)
-    }
-#undef NQ_HF_STEP
-  } else {
   load_x(0, vA, eA);
   load_w(0, wA);
 #pragma unroll 1
@@ -320,7 +291,6 @@ __global__ __launch_bounds__(256) void head_fwd2_kernel(const float* __restrict_
     __builtin_amdgcn_sched_barrier(0);
   }
   if (Cin & 1) compute(vA, eA, wA);      // set A holds the last channel
-  }
 
   float bv[NCO];
 #pragma unroll
@@ -715,16 +685,10 @@ int nq_head_forward(const float* x, const float* wt, int ld, const float* bias, 
     dim3 g2((unsigned)((waves + 3) / 4)), blk2(256);
     const size_t lds = 0;
     const bool th = epi == NQ_EPI_TANH;
-    static const int pd = [] { const char* e = getenv("NQ_HEAD_PD"); return e ? atoi(e) : 2; }();   // channels in flight ahead
 #define NQ_HF2(R_)                                                                                              \
   if (R == R_) {                                                                                                \
-    if (pd == 1) {                                                                                              \
-      if (th) hipLaunchKernelGGL((head_fwd2_kernel<R_, 3, true, false, 1>), g2, blk2, lds, st, x, wt, bias, y, a, HeadLossArgs{});  \
-      else hipLaunchKernelGGL((head_fwd2_kernel<R_, 3, false, false, 1>), g2, blk2, lds, st, x, wt, bias, y, a, HeadLossArgs{});    \
-    } else {                                                                                                    \
-      if (th) hipLaunchKernelGGL((head_fwd2_kernel<R_, 3, true>), g2, blk2, lds, st, x, wt, bias, y, a, HeadLossArgs{});            \
-      else hipLaunchKernelGGL((head_fwd2_kernel<R_, 3, false>), g2, blk2, lds, st, x, wt, bias, y, a, HeadLossArgs{});              \
-    }                                                                                                           \
+    if (th) hipLaunchKernelGGL((head_fwd2_kernel<R_, 3, true>), g2, blk2, lds, st, x, wt, bias, y, a);          \
+    else hipLaunchKernelGGL((head_fwd2_kernel<R_, 3, false>), g2, blk2, lds, st, x, wt, bias, y, a);            \
     return nq_launch_status();                                                                                  \
   }
     NQ_HF2(4)
@@ -764,11 +728,7 @@ int nq_head_forward_loss(const float* x, const float* wt, int ld, const float* b
   la.gcoef = (float)(2.0 / (double)mean_count) * gscale;
   const int waves = B * a.strips * a.rblocks;
   hipStream_t st = nq_s(stream);
-  static const int pd = [] { const char* e = getenv("NQ_HEAD_PD"); return e ? atoi(e) : 2; }();
-  if (pd == 1)
-    hipLaunchKernelGGL((head_fwd2_kernel<R, 3, true, true, 1>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, x, wt, bias, y, a, la);
-  else
-    hipLaunchKernelGGL((head_fwd2_kernel<R, 3, true, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, x, wt, bias, y, a, la);
+  hipLaunchKernelGGL((head_fwd2_kernel<R, 3, true, true>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, x, wt, bias, y, a, la);
   hipLaunchKernelGGL(head_loss_stage2, dim3(4), dim3(256), 0, st, ws, waves, (float)(1.0 / (double)mean_count), loss, db);
   return nq_launch_status();
 }
