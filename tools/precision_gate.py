@@ -62,14 +62,14 @@ def make_order(n, B, iters, seed=903):
     return torch.stack([torch.randperm(n, generator=g)[: (n // B) * B].view(n // B, B) for _ in range(n_ep)]).numpy()
 
 
-def load_fixture_checkpoint(name, dev):
+def load_fixture_checkpoint(name, dev, arch="hnerv"):
     """(model, emb, fp_psnr) from a committed decoder checkpoint fixture (tests/golden/<name>: fp16-grid decoder weights +
     embeddings, made by tests/golden/make_ckpt_fixture.py); the encoder stays at its initial values -- calibration and
     evaluation only consume the decoder and the embeddings."""
-    from neuroquant_amd.models import HNeRV
+    from neuroquant_amd.models import HNeRV, NeRV
     z = np.load(os.path.join(ROOT, "tests", "golden", name))
     torch.manual_seed(903)
-    model = HNeRV(HNERV_3M)
+    model = HNeRV(HNERV_3M) if arch == "hnerv" else NeRV(NERV_3M)
     sd = {k[3:].replace("/", "."): torch.from_numpy(z[k].astype(np.float32)) for k in z.files if k.startswith("sd:")}
     missing, unexpected = model.load_state_dict(sd, strict=False)
     assert not unexpected and all(m.startswith("encoder") for m in missing), (missing, unexpected)
@@ -209,7 +209,7 @@ def run(args, log=print):
         frames_u8 = synthetic_frames(n, 640, 1280, seed=903, device=dev)
     n = frames_u8.shape[0]
     if args.ckpt and args.ckpt.endswith(".npz"):
-        model, emb, fp_psnr = load_fixture_checkpoint(os.path.basename(args.ckpt), dev)
+        model, emb, fp_psnr = load_fixture_checkpoint(os.path.basename(args.ckpt), dev, arch=args.arch)
         from neuroquant_amd import ops
         with torch.no_grad():   # what THIS decoder (fp16-grid weights) decodes to
             fp_psnr = float(torch.cat([ops.frame_psnr(model.decode(emb[i:i + 1])[0], frames_u8[i:i + 1].float() / 255.0)
