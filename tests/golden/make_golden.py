@@ -26,6 +26,8 @@ Fixtures (what each one pins; reference file:line):
   traj_nerv_had.npz  tiny NeRV + Hadamard: same (FWHT via stub -> "parity unpinned" at the transform)
   config1_hnerv3m.npz  BASELINE configs[0] at FULL size with the real reference: HNeRV-3M (trained checkpoint
                      hnerv3m_bunny8_f16.npz), 8 frames of 640x1280, 48 iterations: loss log + PSNRs     calib_model.py:92-240
+  config1_hnerv3m_long.npz  the real reference for 3000 iterations at full size (148 phase-1 + 2852 phase-2), every loss, final
+                     PSNRs / scales / masks                                                               calib_model.py:92-240
   config2_nerv3m_hadamard.npz   BASELINE configs[2] at FULL size with the real reference: NeRV-3M + --hadamard (trained
                      checkpoint nerv3m_bunny8real_f16.npz), the 8 real 640x1280 crops, 48 iterations            quant_layer.py:44-49, 70-71
   config1_hnerv3m_hadamard.npz  the same for HNeRV-3M + --hadamard on hnerv3m_bunny8real_f16.npz                 calib_model.py:170-191
@@ -754,6 +756,79 @@ def gen_fullsize_hadamard(name, arch, ckpt_name):
     save(name, **out)
 
 
+def gen_config1_long(iters=3000):
+    """Round 4: the REAL reference over thousands of iterations at full size, phase 1 included (the
+    full-size reference evidence stopped at 48 phase-2 iterations).  HNeRV Bunny_1280x640_3M, checkpoint
+    hnerv3m_bunny8real_f16.npz (FP 38.07 dB), the eight real 640x1280 crops, --precision 6 5 4 5 5 6 6, batch 2, iters_w = 3000
+    -> int(0.05*3000/4) = 37 phase-1 epochs (148 iterations) + 713 phase-2 epochs (2852 iterations) of the reference's own
+    model_reconstruction.  Stored: batch order, every iteration's (total, round, b, count), PSNRs FP / w/o opt / w/ opt, the
+    scales after phase 1 (= final: phase 2 does not step them) and the final hard-rounding masks.  ~2 h on 6 threads."""
+    torch.set_num_threads(6)
+    ck = np.load(os.path.join(HERE, "hnerv3m_bunny8real_f16.npz"))
+    frames = torch.from_numpy(np.load(os.path.join(HERE, "bunny8_640x1280.npz"))["frames"].copy()).float() / 255.0
+    n, B = frames.shape[0], 2
+    torch.manual_seed(1)
+    model = HNeRV(HNERV_3M)
+    sd = {k[3:].replace("/", "."): torch.from_numpy(ck[k].astype(np.float32)) for k in ck.files if k.startswith("sd:")}
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    assert not unexpected and all(m.startswith("encoder") for m in missing), (missing, unexpected)
+    model.eval()
+    emb = torch.from_numpy(ck["emb"].astype(np.float32))
+    out = {}
+    with torch.no_grad():
+        y_fp = torch.cat([model.decode(emb[i:i + 1])[0] for i in range(n)], 0)
+    out["psnr_fp"] = npy(psnr_frames(y_fp, frames))
+    qnn = QuantModel(model=model, hadamard=False, weight_quant_params=dict(n_bits=8, channel_wise=True, scale_method="max"))
+    out["avgbits"] = np.array(qnn.set_bitwidth(BITS), dtype=np.float64)
+    qnn.eval()
+    qnn.set_quant_state(True)
+    with torch.no_grad():
+        qnn(emb[:B])
+        y_q0 = torch.cat([qnn(emb[i:i + 1])[0] for i in range(n)], 0)
+    out["psnr_q_noopt"] = npy(psnr_frames(y_q0, frames))
+    print("  FP / w/o opt psnr", out["psnr_fp"].mean(), out["psnr_q_noopt"].mean(), flush=True)
+    g = torch.Generator().manual_seed(903)
+    n_ep = iters // (n // B)
+    order = torch.stack([torch.randperm(n, generator=g)[: (n // B) * B].view(n // B, B) for _ in range(n_ep)]).numpy()
+    out["order"] = order.astype(np.int16)
+    loader = ReplayLoader(frames, order, n)
+    log = []
+    orig_call = ref_calib.LossFunction.__call__
+
+    def recording_call(self, pred, tgt, grad=None):
+        total = orig_call(self, pred, tgt, grad)
+        b = self.temp_decay(self.count)
+        if self.count < self.loss_start or self.round == "none":
+            b = 0
+        log.append((float(total), float(self.round_loss), float(b), self.count))
+        if len(log) % 100 == 0:
+            print(f"    iteration {len(log)}: total {log[-1][0]:.5f}, {time.time() - t0:.0f}s", flush=True)
+        return total
+
+    ref_calib.LossFunction.__call__ = recording_call
+    t0 = time.time()
+    try:
+        ref_calib.model_reconstruction(qnn, cali_data=emb, gt=loader, arch="hnerv", batch_size=B, iters=iters, weight=0.01,
+                                       opt_mode="mse", hadamard=False, b_range=(20, 2), warmup=0.2, p=2.0, lr=0.003)
+    finally:
+        ref_calib.LossFunction.__call__ = orig_call
+    print(f"  model_reconstruction: {len(log)} iterations in {time.time() - t0:.1f}s", flush=True)
+    out["loss_log"] = np.array(log, dtype=np.float64)
+    out["iters"] = np.array(iters)
+    out["seconds_cpu6"] = np.array(time.time() - t0)
+    qms = [m for m in qnn.model.modules() if isinstance(m, QuantModule)]
+    for li, m in enumerate(qms):
+        out[f"mask{li}"] = np.packbits((m.weight_quantizer.alpha.detach() >= 0).numpy().reshape(-1))
+        out[f"final_wdelta{li}"] = npy(m.weight_quantizer.delta)
+        out[f"final_bdelta{li}"] = npy(m.bias_quantizer.delta)
+    qnn.set_quant_state(True)
+    with torch.no_grad():
+        y_q1 = torch.cat([qnn(emb[i:i + 1])[0] for i in range(n)], 0)
+    out["psnr_q_opt"] = npy(psnr_frames(y_q1, frames))
+    print("  quant w/ opt psnr", out["psnr_q_opt"].mean(), flush=True)
+    save("config1_hnerv3m_long.npz", **out)
+
+
 GENS = {
     "uaq": gen_uaq,
     "adaround": gen_adaround,
@@ -768,6 +843,7 @@ GENS = {
     "traj_nerv_had": lambda: gen_traj("traj_nerv_had.npz", "nerv", NeRV, TINY_NERV, True, 200, 150, 2e-3, 904),
     "omega": gen_omega,
     "config1": gen_config1,
+    "config1_long": gen_config1_long,
     "config2": lambda: gen_fullsize_hadamard("config2_nerv3m_hadamard.npz", "nerv", "nerv3m_bunny8real_f16.npz"),
     "config1_hadamard": lambda: gen_fullsize_hadamard("config1_hnerv3m_hadamard.npz", "hnerv", "hnerv3m_bunny8real_f16.npz"),
 }
