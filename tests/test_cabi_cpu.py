@@ -72,6 +72,26 @@ def test_wgrad3_plan_keeps_big_operands_off_the_32bit_offset_kernel():
     assert lib.nq_conv_wgrad3_plan(2, 44, 320, 640, 148, 7, *[ctypes.byref(ctypes.c_int()) for _ in range(4)]) == -1
 
 
+def test_few_pixel_layers_are_routed_to_the_flat_kernels():
+    """Round 4 launch plans, host-only (pure functions of the shape): the deep layers of both 3M models go to the few-pixel
+    kernels (conv_flat3.hip: no slabs for a forward; conv_wgrad_flat3.hip: no slabs at all), toy convolutions stay on the
+    exact-fp32 kernels, the big layers keep the tiled kernels, and a 3-chunk K loop is no longer split."""
+    from neuroquant_amd import _lib
+    lib = _lib.lib()
+    for B, cin, H, W, cout, k in [(2, 77, 10, 20, 1024, 3), (2, 145, 2, 4, 1800, 3), (2, 72, 10, 20, 576, 3)]:
+        assert lib.nq_conv3_supported(B, cin, H, W, cout, k) == 1
+        assert lib.nq_conv_forward3_ws_floats(B, cin, H, W, cout, k) == 0          # forward: no slabs, no finish launch
+        assert lib.nq_conv_wgrad3_supported(B, cin, H, W, cout, k) == 1
+        assert lib.nq_conv_wgrad3_ws_floats(B, cin, H, W, cout, k) == 4            # a token workspace
+    assert lib.nq_conv3_supported(2, 5, 6, 7, 8, 3) == 0                             # a toy layer: exact fp32
+    assert lib.nq_conv_wgrad3_supported(2, 5, 6, 8, 8, 3) == 0
+    assert lib.nq_conv_forward3_ws_floats(2, 44, 320, 640, 148, 5) == 0              # dec5: enough tiles
+    assert lib.nq_conv_wgrad3_ws_floats(2, 44, 320, 640, 148, 5) > 1 << 20           # ... and split-K slabs for its weight gradient
+    assert lib.nq_conv_forward3_ws_floats(2, 36, 40, 80, 384, 3) == 0                # NeRV dec3 forward: 3 chunks, not split (was 2 slabs)
+    assert lib.nq_conv_forward3_ws_floats(2, 848, 40, 80, 64, 5) > 0                 # HNeRV dec3 data gradient: 53 chunks, split
+    assert lib.nq_head_forward_loss_ws_floats(2, 640, 1280) == 2 * 5 * 160 * 4       # 4 floats per (frame, 256-column strip, 4-row block)
+
+
 def test_ops_refuse_cpu_tensors():
     from neuroquant_amd import ops
     with pytest.raises(RuntimeError):
