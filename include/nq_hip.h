@@ -274,6 +274,9 @@ typedef struct nq_wl3_seg {
   int Cin, Cout, k, transposed;
 } nq_wl3_seg;
 NQ_API int nq_weight_layout3_multi(const nq_wl3_seg* segs, int nseg, nq_stream_t stream);
+/* nq_weight_layout3_multi + nq_weight_layouts_multi in ONE launch (ABI v4): every operand a decoder needs per iteration, the
+ * same bytes as the two calls (which it falls back to when a table does not fit one kernel-argument block). */
+NQ_API int nq_weight_layouts_all(const nq_wl3_seg* segs3, int n3, const nq_wl_seg* segsf, int nf, nq_stream_t stream);
 NQ_API int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* y, float* z, const float* zprev, float* ws, int B,
                      int Cin, int H, int W, int Cout, int k, int r, int epilogue, nq_stream_t stream);
 

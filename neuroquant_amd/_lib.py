@@ -122,6 +122,7 @@ def _load():
     sig("nq_weight_layout3", I, P, P, I, I, I, I, P)
     sig("nq_weight_layout3_multi", I, POINTER(WL3Seg), I, P)
     sig("nq_weight_layouts_multi", I, POINTER(WLSeg), I, P)
+    sig("nq_weight_layouts_all", I, POINTER(WL3Seg), I, POINTER(WLSeg), I, P)
     sig("nq_conv_forward3_ws_floats", L, I, I, I, I, I, I)
     sig("nq_conv_forward3", I, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P)
     sig("nq_conv_wgrad3_supported", I, I, I, I, I, I, I)
@@ -162,7 +163,7 @@ EXPORTS = (
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",
     "nq_channel_sum", "nq_l2_loss_tanh_head", "nq_frame_sse", "nq_gather_frames_u8",
     "nq_act_dd", "nq_pixel_shuffle", "nq_bias_add", "nq_head_forward_loss_ws_floats", "nq_head_forward_loss",
-    "nq_adaround_fwht_multi", "nq_fwht_adaround_adam_multi",
+    "nq_adaround_fwht_multi", "nq_fwht_adaround_adam_multi", "nq_weight_layouts_all",
 )
 
 _lib = None

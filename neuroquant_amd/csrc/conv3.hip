@@ -165,6 +165,50 @@ __global__ __launch_bounds__(256) void weight_layout3_multi_kernel(WL3Multi t) {
   else wl3_tile<9>(t.s[k], blk / t.s[k].co16, blk % t.s[k].co16, T);
 }
 
+// Round 4: the fp32 operands of the layers that stay on the fp32 / vector kernels (the 1 x 1 stem, the head) in the SAME launch
+// as the bf16x3 operands: blocks past the bf16x3 tiles run the element code of weight_layouts_multi_kernel (conv.hip) -- the
+// same values, one launch (~5 us of launch floor) less per iteration.
+struct WLF {
+  const float* w;
+  float* wt;
+  int Cout, Cin, KK, krows, ld, bwd;
+};
+struct WLAll {
+  WL3 s3[WL3_MAXSEG];
+  int blk3[WL3_MAXSEG + 1];
+  int n3;
+  WLF sf[WL3_MAXSEG];
+  int blkf[WL3_MAXSEG + 1];
+  int nf;
+};
+__global__ __launch_bounds__(256) void weight_layouts_all_kernel(WLAll t) {
+  __shared__ float T[16 * (16 * WL3_KKMAX + 1)];
+  const int nb3 = t.blk3[t.n3];
+  if ((int)blockIdx.x < nb3) {
+    int k = 0;
+    while (k + 1 < t.n3 && (int)blockIdx.x >= t.blk3[k + 1]) ++k;
+    const int blk = (int)blockIdx.x - t.blk3[k];
+    if (t.s3[k].KK == 25) wl3_tile<25>(t.s3[k], blk / t.s3[k].co16, blk % t.s3[k].co16, T);
+    else wl3_tile<9>(t.s3[k], blk / t.s3[k].co16, blk % t.s3[k].co16, T);
+    return;
+  }
+  const int bf = (int)blockIdx.x - nb3;
+  int k = 0;
+  while (k + 1 < t.nf && bf >= t.blkf[k + 1]) ++k;
+  const WLF& g = t.sf[k];
+  const int64_t i = (int64_t)(bf - t.blkf[k]) * 256 + threadIdx.x;
+  if (i >= (int64_t)g.krows * g.ld) return;
+  const int row = (int)(i / g.ld), col = (int)(i - (int64_t)row * g.ld);
+  float v = 0.f;
+  if (g.bwd) {   // wt[(co*KK + tap')][ci] = w[co][ci][KK-1-tap']
+    const int co = row / g.KK, tap = row - co * g.KK;
+    if (co < g.Cout && col < g.Cin) v = g.w[((int64_t)co * g.Cin + col) * g.KK + (g.KK - 1 - tap)];
+  } else {       // wt[k][co] = w[co][k]
+    if (col < g.Cout && row < g.Cin * g.KK) v = g.w[(int64_t)col * (g.Cin * g.KK) + row];
+  }
+  g.wt[i] = v;
+}
+
 // split-K of the forward / data-gradient kernel over 16-channel chunks when the pixel x channel grid alone cannot fill
 // the chip (deep, low-resolution layers): ~512 workgroups, every split non-empty
 struct Fwd3Plan {
@@ -462,6 +506,49 @@ int nq_weight_layout3_multi(const nq_wl3_seg* segs, int nseg, nq_stream_t stream
     t.blk0[t.nseg] = blocks;
     hipLaunchKernelGGL(weight_layout3_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, nq_s(stream), t);
   }
+  return nq_launch_status();
+}
+
+int nq_weight_layouts_all(const nq_wl3_seg* segs3, int n3, const nq_wl_seg* segsf, int nf, nq_stream_t stream) {
+  if ((n3 > 0 && !segs3) || (nf > 0 && !segsf) || n3 < 0 || nf < 0 || n3 + nf == 0) return NQ_ERR_INVALID;
+  // count the fp32 operands (one per direction)
+  int nfo = 0;
+  for (int i = 0; i < nf; ++i) nfo += (segsf[i].wt_fwd ? 1 : 0) + (segsf[i].wt_bwd ? 1 : 0);
+  if (n3 > WL3_MAXSEG || nfo > WL3_MAXSEG || n3 == 0 || nfo == 0) {   // does not fit one argument block: the two launches
+    if (n3 > 0)
+      if (int rc = nq_weight_layout3_multi(segs3, n3, stream)) return rc;
+    if (nf > 0) return nq_weight_layouts_multi(segsf, nf, stream);
+    return NQ_OK;
+  }
+  WLAll t;
+  t.n3 = n3;
+  int blocks = 0;
+  for (int i = 0; i < n3; ++i) {
+    const nq_wl3_seg& h = segs3[i];
+    if (!wl3_fill(t.s3[i], h.w, h.wt3, h.Cin, h.Cout, h.k, h.transposed)) return NQ_ERR_INVALID;
+    t.blk3[i] = blocks;
+    blocks += t.s3[i].nchunk * t.s3[i].co16;
+  }
+  t.blk3[n3] = blocks;
+  t.nf = 0;
+  int bf = 0;
+  for (int i = 0; i < nf; ++i) {
+    const nq_wl_seg& h = segsf[i];
+    if (!h.w || h.Cout <= 0 || h.Cin <= 0 || h.k <= 0) return NQ_ERR_INVALID;
+    const int KK = h.k * h.k;
+    for (int bwd = 0; bwd < 2; ++bwd) {
+      float* wt = bwd ? h.wt_bwd : h.wt_fwd;
+      if (!wt) continue;
+      const int krows = bwd ? h.krows_bwd : h.krows_fwd, ld = bwd ? h.ld_bwd : h.ld_fwd;
+      if (bwd ? (krows < h.Cout * KK || ld < h.Cin) : (krows < h.Cin * KK || ld < h.Cout)) return NQ_ERR_INVALID;
+      t.sf[t.nf] = WLF{h.w, wt, h.Cout, h.Cin, KK, krows, ld, bwd};
+      t.blkf[t.nf] = bf;
+      bf += (int)(((int64_t)krows * ld + 255) / 256);
+      ++t.nf;
+    }
+  }
+  t.blkf[t.nf] = bf;
+  hipLaunchKernelGGL(weight_layouts_all_kernel, dim3((unsigned)(blocks + bf)), dim3(256), 0, nq_s(stream), t);
   return nq_launch_status();
 }
 

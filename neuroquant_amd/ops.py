@@ -561,6 +561,39 @@ def weight_layouts_multi(items):
     return outs
 
 
+def weight_layouts_all(items3, items_f):
+    """weight_layout3_multi(items3) and weight_layouts_multi(items_f) in ONE launch (nq_weight_layouts_all; same bytes)."""
+    if not items3 or not items_f or os.environ.get("NQ_LAYOUTS_ALL", "1") == "0":
+        return weight_layout3_multi(items3), weight_layouts_multi(items_f)
+    segs3 = (L.WL3Seg * len(items3))()
+    outs3 = []
+    for sg, (w, transposed) in zip(segs3, items3):
+        w = _dev(w)
+        cw_out, cw_in, k, _ = w.shape
+        cin, cout = (cw_out, cw_in) if transposed else (cw_in, cw_out)
+        buf = torch.empty(_q("nq_conv3_weight_bytes", cin, cout, k), device=w.device, dtype=torch.uint8)
+        outs3.append(buf)
+        sg.w, sg.wt3, sg.Cin, sg.Cout, sg.k, sg.transposed = _p(w), _p(buf), cin, cout, k, int(bool(transposed))
+    segsf = (L.WLSeg * len(items_f))()
+    outsf = []
+    for sg, (w, need_fwd, need_bwd) in zip(segsf, items_f):
+        w = _dev(w)
+        cout, cin, k, _ = w.shape
+        wt = wb = None
+        kf = lf = kb = lb = 0
+        if need_fwd:
+            kf, lf = conv_operand_dims(cin, cout, k)
+            wt = torch.empty(kf * lf, device=w.device, dtype=torch.float32)
+        if need_bwd:
+            kb, lb = conv_operand_dims(cout, cin, k)
+            wb = torch.empty(kb * lb, device=w.device, dtype=torch.float32)
+        sg.w, sg.wt_fwd, sg.wt_bwd, sg.Cout, sg.Cin, sg.k = _p(w), _p(wt), _p(wb), cout, cin, k
+        sg.krows_fwd, sg.ld_fwd, sg.krows_bwd, sg.ld_bwd = kf, lf, kb, lb
+        outsf.append((wt, (kf, lf), wb, (kb, lb)))
+    L.check(L.lib().nq_weight_layouts_all(segs3, len(items3), segsf, len(items_f), _stream()), "weight_layouts_all")
+    return outs3, outsf
+
+
 def conv_forward_raw(x, wt, dims, bias, cout, k, epilogue, r, in_gelu=False, zprev=None):
     """One nq_conv_forward launch.  Returns (y, z): z = shuffled pre-activation for the PixelShuffle epilogues
     (y is None for EPI_PS), y = un-shuffled gradient for EPI_DGRAD_GELU."""
@@ -1219,14 +1252,14 @@ class _DecoderStackFn(Function):
             if l == 0:
                 Hx, Wx = Hx * spec.fc_hw[0], Wx * spec.fc_hw[1]
             Hx, Wx = Hx * r, Wx * r
-        operands = weight_layout3_multi(items)
-        # the fp32 operands (layers / directions that stay on the fp32 kernels), all from ONE launch as well.
+        # the fp32 operands (layers / directions that stay on the fp32 kernels) come from the SAME launch (round 4).
         # layer 0's data-gradient operand is only needed when the embedding itself is trained (FP32 trainer: the
         # ConvNeXt encoder sits below it, reference regress.py:259-266)
         need_bs = [(l > 0 and not plan[l][1]) or (l == 0 and ctx.needs_input_grad[0]) for l in range(n)]
         fp32_items = [(_dev(wb[2 * l], "weight"), not plan[l][0], need_bs[l]) for l in range(n)
                       if (not plan[l][0]) or need_bs[l]]
-        fp32_ops = iter(weight_layouts_multi(fp32_items))
+        operands, fp32_list = weight_layouts_all(items, fp32_items)
+        fp32_ops = iter(fp32_list)
         for l, (k, r, act) in enumerate(spec.layers):
             W = _dev(wb[2 * l], "weight")
             b = _dev(wb[2 * l + 1], "bias") if wb[2 * l + 1] is not None else None

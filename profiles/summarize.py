@@ -16,7 +16,7 @@ import sys
 
 
 def kname(n):
-    m = re.search(r"(fwht_adaround_adam_multi_kernel|adaround_fwht_multi_kernel|conv_wgrad_flat3_kernel|conv_flat3_kernel|head_loss_stage2|conv_igemm3_kernel|conv_wgrad3p_kernel|conv_wgrad3_kernel|wgrad3_reduce_kernel|wgrad_reduce_multi_kernel|adaround_adam_multi_kernel|step_prologue\w*|uaq_\w+_multi_kernel|fwht_multi_kernel|l2_tanh_head_stage\d|weight_layouts_multi_kernel|weight_layout3_multi_kernel|weight_layout3_kernel|adaround_multi_kernel|adam_multi_kernel|channel_sum_stage\d|conv_igemm_kernel|conv_wgrad_kernel|head_\w+_kernel|conv_splitk_finish_kernel|tiny_pw_\w+_kernel|wgrad_reduce_kernel|"
+    m = re.search(r"(fwht_adaround_adam_multi_kernel|adaround_fwht_multi_kernel|weight_layouts_all_kernel|conv_wgrad_flat3_kernel|conv_flat3_kernel|head_loss_stage2|conv_igemm3_kernel|conv_wgrad3p_kernel|conv_wgrad3_kernel|wgrad3_reduce_kernel|wgrad_reduce_multi_kernel|adaround_adam_multi_kernel|step_prologue\w*|uaq_\w+_multi_kernel|fwht_multi_kernel|l2_tanh_head_stage\d|weight_layouts_multi_kernel|weight_layout3_multi_kernel|weight_layout3_kernel|adaround_multi_kernel|adam_multi_kernel|channel_sum_stage\d|conv_igemm_kernel|conv_wgrad_kernel|head_\w+_kernel|conv_splitk_finish_kernel|tiny_pw_\w+_kernel|wgrad_reduce_kernel|"
                   r"weight_\w+_layout_kernel|adaround_\w+_kernel|uaq_\w+_kernel|adam_kernel|l2_loss_stage1|nq_sum_stage2|"
                   r"tanh_out_bwd_kernel|gather_u8_kernel|fwht_kernel|round_loss\w*|ps_gelu_bwd_kernel|frame_sse_kernel|"
                   r"scale_init_kernel)(<[^>]*>)?", n)
