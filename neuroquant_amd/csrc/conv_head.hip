@@ -160,9 +160,16 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 // used as the SGPR operand of v_pk_fma_f32.  A first version (input rows outermost, three accumulator rows, a load queue) was
 // bound by instruction ISSUE at ~1.25 waves per SIMD: 66 bookkeeping instructions per 54 v_pk_fma; this order has ~13.
 // Per output the fp32 fused multiply-adds run in (ci, kh, kw) order, as in head_fwd_kernel.
+// cache-hot-first wave order of head_fwd2_kernel (see there): needs 8 whole bands of row blocks and whole workgroups per XCD
+// chunk; NQ_HEAD_HOT=0 restores the top-down order (A/B runs)
+static inline int head_hot_first(int B, int strips, int rblocks) {
+  static const int on = [] { const char* e = getenv("NQ_HEAD_HOT"); return e ? atoi(e) : 1; }();
+  return (on && B >= 1 && B <= 8 && 8 % B == 0 && rblocks % (8 / B) == 0 && (B * strips * rblocks) % 32 == 0) ? 1 : 0;
+}
 struct HeadFwd2Args {
   int B, Cin, H, W, ld, strips, rblocks;
   unsigned x_bytes;
+  int hot_first;
 };
 // Round 4: the loss tail fused behind the head (LOSS = true).  The wave that owns a strip of the image has every output pixel of
 // it in registers: lp_loss (quantizer.py:66-71), the tanh backward of OutImg (_layers.py:10-16) and the head's bias gradient
@@ -192,8 +199,19 @@ __global__ __launch_bounds__(256) void head_fwd2_kernel(const float* __restrict_
   const int total = a.B * a.strips * a.rblocks;
   const int wid = nq_xcd_chunk((int)blockIdx.x, (int)gridDim.x) * 4 + wave;
   if (wid >= total) return;   // whole wave
-  const int by = wid % a.rblocks, t0 = wid / a.rblocks;
-  const int sx = t0 % a.strips, b = t0 / a.strips;
+  int by = wid % a.rblocks, t0 = wid / a.rblocks;
+  int sx = t0 % a.strips, b = t0 / a.strips;
+  if (a.hot_first) {
+    // Round 4: the producer (the last block's forward convolution, XCD-chunked) wrote this tensor as 8 row bands, one per XCD,
+    // each from its top row down, so the END of every band is what the 256 MB memory-side cache still holds when this kernel
+    // starts.  XCD k walks band k from its last rows upwards (strips fastest) instead of top-down: the same waves on the same
+    // operands (identical results), 85 -> 78 us inside an HNeRV-3M iteration, 65 -> 60 us for NeRV-3M (same-box A/B, twice).
+    const int q = total >> 3, k = wid / q, i = wid - k * q;
+    const int bands = 8 / a.B, rows_per_band = a.rblocks / bands;
+    b = k / bands;
+    by = (k - b * bands) * rows_per_band + (rows_per_band - 1 - i / a.strips);
+    sx = i % a.strips;
+  }
   const int H = a.H, W = a.W, Cin = a.Cin;
   const int y0 = by * R, x0 = sx * 256, gx = x0 + 4 * lane;
   const unsigned HWb = (unsigned)H * (unsigned)W * 4u, Wb = (unsigned)W * 4u;
@@ -681,6 +699,7 @@ int nq_head_forward(const float* x, const float* wt, int ld, const float* bias, 
     a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.ld = ld;
     a.strips = (W + 255) / 256; a.rblocks = (H + R - 1) / R;
     a.x_bytes = (unsigned)((int64_t)B * Cin * H * W * 4);
+    a.hot_first = head_hot_first(B, a.strips, a.rblocks);
     const int waves = B * a.strips * a.rblocks;
     dim3 g2((unsigned)((waves + 3) / 4)), blk2(256);
     const size_t lds = 0;
@@ -723,6 +742,7 @@ int nq_head_forward_loss(const float* x, const float* wt, int ld, const float* b
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.ld = ld;
   a.strips = (W + 255) / 256; a.rblocks = (H + R - 1) / R;
   a.x_bytes = (unsigned)((int64_t)B * Cin * H * W * 4);
+  a.hot_first = head_hot_first(B, a.strips, a.rblocks);
   HeadLossArgs la;
   la.tgt = tgt; la.cache = cache_u8; la.idx = idx; la.dconv = dconv; la.ws = ws;
   la.gcoef = (float)(2.0 / (double)mean_count) * gscale;
