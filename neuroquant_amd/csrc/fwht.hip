@@ -29,6 +29,10 @@ constexpr int FW_MAXSEG_FQ = 16;
 #ifndef NQ_FWHT_COLS
 #define NQ_FWHT_COLS 16
 #endif
+#ifndef NQ_FWHT_U
+#define NQ_FWHT_U 3
+#endif
+constexpr int FQ_U = NQ_FWHT_U;                // elements per thread and round of the fused launches' element loops
 constexpr int TILE = NQ_FWHT_TILE;             // floats of a workgroup's tile (n * columns)
 constexpr int LDS_FLOATS = TILE + 1024;    // n * (columns + 1) floats, n <= 1024
 
@@ -272,34 +276,57 @@ __device__ __forceinline__ void fwht_ada_adam_tile(float* lds, int blk, const Fq
   __syncthreads();
   fwht_stages(lds, n, g.log2n, TC, LD);
   {
+    // d(alpha) + Adam over the tile, FQ_U elements per thread and round: ALL of a round's global loads are issued before its
+    // first store (the stores to m / v / alpha may alias the next loads as far as the compiler knows, so one element per loop
+    // iteration was one exposed memory round trip per element -- 16 per workgroup and launch).  Elements past the tile load
+    // the tile's last element (unconditional loads, no branches) and store nothing.  Same arithmetic per element.
     const int per_o = n * inner, total = nob * per_o;
     const int64_t base = o0 * per_o;
     const bool pow2 = (g.log2n & 1) == 0;
     const float inv = 1.0f / g.sqrt_n;
     int ol = threadIdx.x / per_o, r = threadIdx.x - ol * per_o;
     int c = r / inner, ii = r - c * inner;
-    for (int e = threadIdx.x; e < total; e += TPB) {
-      const float t = lds[c * LD + ol * inner + ii];
-      const float gv = pow2 ? t * inv : t / g.sqrt_n;          // what nq_fwht stores
-      const int64_t i = base + e;
-      const int64_t row = g.per_row ? o0 + ol : 0;
-      const float gr = ada_bwd_elem(g.x[i], gv, g.alpha[i], g.delta[row], g.zp[row], g.qmax, rw, reg_b);
-      float mi = g.m[i], vi = g.v[i];
-      mi = mi + (1.f - beta1) * (gr - mi);
-      vi = vi * beta2 + (1.f - beta2) * (gr * gr);
-      const float denom = sqrtf(vi) / bc2_sqrt + eps;
-      g.m[i] = mi;
-      g.v[i] = vi;
-      g.alpha[i] = g.alpha[i] - step_size * (mi / denom);
-      ii += d_i;
-      c += d_c;
-      if (ii >= inner) {
-        ii -= inner;
-        ++c;
+    for (int e0 = threadIdx.x; e0 < total; e0 += FQ_U * TPB) {
+      float xv[FQ_U], av[FQ_U], mv[FQ_U], vv[FQ_U], dl[FQ_U], zq[FQ_U], tv[FQ_U];
+#pragma unroll
+      for (int u = 0; u < FQ_U; ++u) {
+        const int e = e0 + u * TPB;
+        const bool ok = e < total;
+        const int64_t i = base + (ok ? e : total - 1);
+        const int64_t row = g.per_row ? o0 + (ok ? ol : nob - 1) : 0;
+        xv[u] = g.x[i];
+        av[u] = g.alpha[i];
+        mv[u] = g.m[i];
+        vv[u] = g.v[i];
+        dl[u] = g.delta[row];
+        zq[u] = g.zp[row];
+        tv[u] = lds[ok ? c * LD + ol * inner + ii : 0];
+        ii += d_i;
+        c += d_c;
+        if (ii >= inner) {
+          ii -= inner;
+          ++c;
+        }
+        while (c >= n) {
+          c -= n;
+          ++ol;
+        }
       }
-      while (c >= n) {
-        c -= n;
-        ++ol;
+#pragma unroll
+      for (int u = 0; u < FQ_U; ++u) {
+        const int e = e0 + u * TPB;
+        if (e < total) {
+          const int64_t i = base + e;
+          const float gv = pow2 ? tv[u] * inv : tv[u] / g.sqrt_n;          // what nq_fwht stores
+          const float gr = ada_bwd_elem(xv[u], gv, av[u], dl[u], zq[u], g.qmax, rw, reg_b);
+          float mi = mv[u], vi = vv[u];
+          mi = mi + (1.f - beta1) * (gr - mi);
+          vi = vi * beta2 + (1.f - beta2) * (gr * gr);
+          const float denom = sqrtf(vi) / bc2_sqrt + eps;
+          g.m[i] = mi;
+          g.v[i] = vi;
+          g.alpha[i] = av[u] - step_size * (mi / denom);
+        }
       }
     }
   }
