@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the convolutions of NeRV-3M's last two blocks (B = 2; 96->96 at 160x320 and 24->96 at 320x640, both
-k3 + PixelShuffle 2 + GELU): forward and data gradient, median of interleaved rounds, algorithmic bytes per second.
+"""Micro-benchmark of the convolutions of NeRV-3M's last two blocks (B = 2; 24->96 at 160x320 and 24->96 at 320x640, both
+k3 + PixelShuffle 2 + GELU): forward, data gradient and weight gradient, median of interleaved rounds, algorithmic bytes per second.
 
     python tools/bench_nerv_tail.py           # NQ_IG3_OCC3_STEPS=<n> selects the 3-waves-per-SIMD build for <= n k-steps
 """
@@ -27,7 +27,7 @@ def timeit(fn, n=5):
 def main():
     g = torch.Generator().manual_seed(0)
     cases = []
-    for name, cin, H, W, cout, rp in (("blk5", 24, 320, 640, 96, 2), ("blk4", 96, 160, 320, 96, 4)):
+    for name, cin, H, W, cout, rp in (("blk5", 24, 320, 640, 96, 2), ("blk4", 24, 160, 320, 96, 4)):
         B, k, r = 2, 3, 2
         x = torch.randn(B, cin, H, W, generator=g).cuda()
         w = (torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)).cuda()
@@ -42,6 +42,9 @@ def main():
         cases.append((f"{name} dgrad {cout}->{cin} {H}x{W}", by_d,
                       lambda dy=dy, wt3t=wt3t, cin=cin, rp=rp, zprev=zprev:
                       ops.conv3_forward_raw(dy, wt3t, None, cin, 3, ops.EPI_DGRAD_GELU, rp, zprev=zprev)))
+        by_w = 4.0 * B * H * W * (cin + cout)
+        cases.append((f"{name} wgrad {cin}x{cout} {H}x{W}", by_w,
+                      lambda x=x, dy=dy, cout=cout: ops.conv_wgrad3_raw(x, dy, cout, 3, True)))
     ts = {n: [] for n, _, _ in cases}
     for _ in range(2):
         for n, _, fn in cases:
