@@ -297,12 +297,15 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
     int sy = 1;
     int ns_pc = 256 / tiles;
     const int segs_x = (W + 31) / 32;
+    // segments per workgroup a taller segment must leave (NQ_WGRAD3_MINSEG; 16 until late round 4: NeRV-3M's 24 -> 96 at
+    // 160 x 320 stayed on one-row segments for it, 44.2 us; 12 -> two rows 42.3; 6 -> four rows 41.3; HNeRV dec3 84.0 -> 80.9)
+    static const int minseg = [] { const char* e = std::getenv("NQ_WGRAD3_MINSEG"); return e ? atoi(e) : 6; }();
     if (!wgrad3_ss1() && ns_pc >= 1) {
-      if (H % 4 == 0 && segs_x * (H / 4) * B / ns_pc >= 16) sy = 4;
-      else if (H % 2 == 0 && segs_x * (H / 2) * B / ns_pc >= 16) sy = 2;
+      if (H % 4 == 0 && segs_x * (H / 4) * B / ns_pc >= minseg) sy = 4;
+      else if (H % 2 == 0 && segs_x * (H / 2) * B / ns_pc >= minseg) sy = 2;
     }
     const int nseg_pc = segs_x * (H / sy) * B;
-    if (ns_pc >= 1 && nseg_pc / ns_pc >= 16) {
+    if (ns_pc >= 1 && nseg_pc / ns_pc >= (minseg < 16 ? minseg : 16)) {
       p.pc = sy == 1 ? 1 : 10 + sy;
       p.nsplit = ns_pc;
     }
