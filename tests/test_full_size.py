@@ -345,9 +345,12 @@ def test_config1_long_reference_fixture(golden, prec):
     crops, iters_w = 3000 -> 148 phase-1 + 2852 phase-2 iterations, 2.8 h of CPU).  The calibration is chaotic at the bit
     level (tests/golden/make_sensitivity.py; at this length exact fp32 on the GPU differs from ITSELF by 0.09 dB when the two
     frames of every batch are swapped: 37.3891 vs 37.3005 dB, profiles/r04_precision_gate_3000.json), so what can be held to
-    the reference is: the schedule (b, count) of all 3000 iterations exactly; the losses of the first iterations of phase 1
-    (identical parameters: conv rounding only) tightly and of ALL iterations as a population; and the final PSNR within the
-    spread the algorithm has at this length."""
+    the reference is: the schedule (b, count) of all 3000 iterations exactly; the loss of the first iteration (identical
+    parameters: conv rounding only) tightly and the losses of phase 1 / of the last 500 iterations as populations; the
+    regulariser column all the way; and the final PSNR within the spread the algorithm has at this length.  Measured on the
+    round-4 build: reference 37.2821 dB, GPU fp32 37.3890, bf16x3 37.3318 (the reference sits 0.05 - 0.11 dB from both, as far
+    as exact fp32 sits from itself under a swap of the batch order); the final hard-rounding masks agree to 60 % only --
+    individual rounding decisions are NOT reproducible at this length by anyone, the objective is."""
     import tools_path  # noqa: F401
     import precision_gate as pg
     from neuroquant_amd import ops
@@ -388,11 +391,19 @@ def test_config1_long_reference_fixture(golden, prec):
         assert rel[0] < 2e-5, rel[:4]                                          # iteration 1: identical parameters
         # reconstruction losses (total - round) as populations: phase 1 and the last 500 iterations of phase 2
         rec_g, rec_r = log[:, 0] - log[:, 1], ref[:, 0] - ref[:, 1]
-        for lo, hi in ((0, p1), (iters - 500, iters)):
-            assert abs(rec_g[lo:hi].mean() - rec_r[lo:hi].mean()) <= 0.03 * rec_r[lo:hi].mean(), (lo, hi)
+        # (measured on the round-4 build: phase 1 0.8 % fp32 / 2.0 % bf16x3, last 500 iterations 2.3 % / 1.9 % -- the latter IS the
+        # final PSNR difference, 10 log10(1.023) = 0.10 dB, so its bound is the PSNR bound of 0.2 dB = 4.7 %)
+        pop = []
+        for (lo, hi), bound in (((0, p1), 0.03), ((iters - 500, iters), 0.047)):
+            pop.append(abs(rec_g[lo:hi].mean() - rec_r[lo:hi].mean()) / rec_r[lo:hi].mean())
+            assert pop[-1] <= bound, (lo, hi, pop)
         # the regulariser is a sum over 2.6 M rounding variables: smooth, follows the reference closely all the way
+        # (measured: 0.11 % of its maximum, both precisions)
         on = ref[:, 1] > 0
-        assert np.abs(log[on, 1] - ref[on, 1]).max() <= 0.02 * ref[on, 1].max()
+        reg = np.abs(log[on, 1] - ref[on, 1]).max() / ref[on, 1].max()
+        assert reg <= 0.005, reg
+        print(f"config1_long [{prec}]: reconstruction-loss means, phase 1 / last 500: {pop[0]:.2e} / {pop[1]:.2e} relative; "
+              f"regulariser max deviation {reg:.2e} of its maximum; phase-1 losses max rel {rel[:p1].max():.2e}")
         qnn.set_quant_state(True)
         got, want = float(psnr().mean()), float(z["psnr_q_opt"].mean())
         print(f"config1_long vs reference [{prec}]: first-iteration rel diff {rel[0]:.1e}; final PSNR {got:.4f} vs {want:.4f} dB; "
