@@ -137,6 +137,25 @@ def test_temp_decay():
     assert round(O.temp_decay(19500, 21000, 0.2, 20, 2), 2) == 3.61
 
 
+def test_schedule_of_the_long_reference_run(golden):
+    """The (b, count) columns and the regulariser's warm-up of the REAL reference over 3000 full-size iterations
+    (config1_hnerv3m_long.npz, make_golden.py::gen_config1_long) against the oracle's restatement of the two-phase schedule
+    (calib_model.py:134-142, 170-226; data_utils.py:24-41): phase 1 = int(0.05 * iters / n_batches) epochs without the
+    regulariser, the counter restarts, phase 2 switches the regulariser on at count = warmup * iters."""
+    z = golden("config1_hnerv3m_long.npz")
+    ref, iters, n_batches = z["loss_log"], int(z["iters"]), 4
+    ep1 = int(0.05 * iters / n_batches)
+    want = [(0.0, c) for c in range(1, ep1 * n_batches + 1)]
+    for c in range(1, (int(iters / n_batches) - ep1) * n_batches + 1):
+        want.append((O.temp_decay(c, iters, 0.2, 20, 2) if c >= iters * 0.2 else 0.0, c))
+    want = np.array(want)
+    assert ref.shape == (len(want), 4) and len(want) == 3000
+    np.testing.assert_array_equal(ref[:, 3], want[:, 1])
+    np.testing.assert_allclose(ref[:, 2], want[:, 0], rtol=1e-7, atol=0)   # (the fixture stores the log as float32)
+    on = want[:, 0] > 0
+    assert (ref[~on, 1] == 0).all() and (ref[on, 1] > 0).all()             # regulariser exactly where b is defined
+
+
 # ------------------------------------------------------------------ QuantModule composition
 @pytest.mark.parametrize("shape", ((8, 5, 3), (12, 16, 1), (6, 37, 5)))
 @pytest.mark.parametrize("had", (False, True))
