@@ -246,7 +246,19 @@ NQ_API int nq_conv_operand_dims(int Cin, int Cout, int k, int* krows, int* ld);
 #define NQ_EPI_DGRAD_GELU 4 /* data gradient: y = conv * zprev, zprev (B,Cout,H,W) = the z a NQ_EPI_PS_GELU forward saved
                              * (= gelu' of the pre-activation), stored PixelUnshuffle(r)-ed, i.e. as the
                              * (B,Cout*r*r,H/r,W/r) output gradient of the convolution below */
+/* Split {hi | lo} word interchange between the bf16x3 kernels (ABI v5; OR-ed into `epilogue`): a float v travels as one
+ * 32-bit word {bf16 hi = bf16(v) in the upper half, bf16 lo = bf16(v - hi) in the lower half}, i.e. the two operands the
+ * bf16x3 kernels derive from v when they stage it -- a consumer that is handed the word re-packs halves instead of converting.
+ * Same bytes per element, same NCHW indexing, same results bit for bit.
+ *   NQ_EPI_X_SPLIT : the input x of nq_conv_forward3 holds such words        (where nq_conv3_split_io has the bit)
+ *   NQ_EPI_Y_SPLIT : the output y is written as such words (never z)         (nq_conv3_split_io / nq_conv_split_out)
+ * nq_split_words converts a float tensor to that form (elementwise; for callers that feed such a kernel themselves). */
+#define NQ_EPI_X_SPLIT 0x100
+#define NQ_EPI_Y_SPLIT 0x200
+NQ_API int nq_split_words(const float* x, float* y, int64_t n, nq_stream_t stream);
 NQ_API int64_t nq_conv_forward_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
+/* 1 when nq_conv_forward can write y as split words (NQ_EPI_Y_SPLIT) for this call: the streaming data gradient of the head */
+NQ_API int nq_conv_split_out(int B, int Cin, int H, int W, int Cout, int k, int r, int epilogue, int in_gelu, int has_bias);
 /* in_gelu != 0: x holds pre-activations and exact GELU is applied while the input tile is staged. */
 NQ_API int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y, float* z, float* ws, int B, int Cin, int H,
                     int W, int Cout, int k, int krows, int ld, int r, int epilogue, int in_gelu, const float* zprev,
@@ -263,6 +275,8 @@ NQ_API int nq_conv_forward(const float* x, const float* wt, const float* bias, f
  *   nq_conv_forward3      : same contract as nq_conv_forward (epilogues, zprev); ws = nq_conv_forward3_ws_floats
  *                           floats (0 -> may be NULL): deep low-resolution layers are split over channel chunks */
 NQ_API int nq_conv3_supported(int B, int Cin, int H, int W, int Cout, int k);
+/* bit mask NQ_EPI_X_SPLIT | NQ_EPI_Y_SPLIT: the sides of nq_conv_forward3 that may travel as split words for this shape */
+NQ_API int nq_conv3_split_io(int B, int Cin, int H, int W, int Cout, int k);
 NQ_API int64_t nq_conv_forward3_ws_floats(int B, int Cin, int H, int W, int Cout, int k);
 NQ_API int64_t nq_conv3_weight_bytes(int Cin, int Cout, int k);
 NQ_API int nq_weight_layout3(const float* w, void* wt3, int Cin, int Cout, int k, int transposed, nq_stream_t stream);
@@ -289,6 +303,12 @@ NQ_API int64_t nq_conv_wgrad3_ws_floats(int B, int Cin, int H, int W, int Cout, 
 NQ_API int nq_conv_wgrad3_plan(int B, int Cin, int H, int W, int Cout, int k, int* mi, int* ni, int* nsplit, int* pc);
 NQ_API int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                    int k, nq_stream_t stream);
+/* The same with operands as split {hi | lo} words (see NQ_EPI_X_SPLIT): fmt bit 0 -- x, bit 1 -- dy, only the bits
+ * nq_conv_wgrad3_split_io returns for the shape (the row-segment producer/consumer kernel).  dw is bit-identical to the float
+ * call on the un-split tensors; db sums hi + lo of every dy value (what the matrix pipe sees of it). */
+NQ_API int nq_conv_wgrad3_split_io(int B, int Cin, int H, int W, int Cout, int k);
+NQ_API int nq_conv_wgrad3_fmt(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+                       int k, int fmt, nq_stream_t stream);
 /* The same weight gradient dw (Cout,Cin,k,k) for a convolution with very FEW output channels (the 3-channel head, HNeRV.py:42)
  * by exchanged operand roles: R[ci][(co,tap)] = sum_p x[ci][p] * dy[co][p+tap] is the weight gradient of the convolution
  * dy -> x-channels and dW[co][ci][tap] = R[ci][co][k*k-1-tap]; the big tensor x is then the un-shifted GEMM operand read
@@ -321,6 +341,8 @@ typedef struct nq_wgr_seg {
 } nq_wgr_seg;
 NQ_API int nq_conv_wgrad3_slabs(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                          int k, nq_wgr_seg* seg, nq_stream_t stream);
+NQ_API int nq_conv_wgrad3_slabs_fmt(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W,
+                             int Cout, int k, nq_wgr_seg* seg, int fmt, nq_stream_t stream);   /* fmt: nq_conv_wgrad3_fmt */
 NQ_API int nq_conv_wgrad3_swapped_slabs(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int H, int W, int Cout,
                                  int k, nq_wgr_seg* seg, nq_stream_t stream);
 NQ_API int nq_conv_wgrad_slabs(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NQ_LIB") or os.path.join(_HERE, "libnqhip.so")
 
 NQ_OK = 0
-ABI_VERSION = 4   # nq_abi_version() of the library this binding was written against (include/nq_hip.h)
+ABI_VERSION = 5   # nq_abi_version() of the library this binding was written against (include/nq_hip.h)
 EPI_PLAIN, EPI_PS_GELU, EPI_TANH, EPI_PS, EPI_DGRAD_GELU = 0, 1, 2, 3, 4
 
 
@@ -118,6 +118,12 @@ def _load():
     sig("nq_conv_forward_ws_floats", L, I, I, I, I, I, I)
     sig("nq_conv_forward", I, P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P)
     sig("nq_conv3_supported", I, I, I, I, I, I, I)
+    sig("nq_conv3_split_io", I, I, I, I, I, I, I)
+    sig("nq_conv_split_out", I, I, I, I, I, I, I, I, I, I, I)
+    sig("nq_split_words", I, P, P, L, P)
+    sig("nq_conv_wgrad3_split_io", I, I, I, I, I, I, I)
+    sig("nq_conv_wgrad3_fmt", I, P, P, P, P, P, I, I, I, I, I, I, I, P)
+    sig("nq_conv_wgrad3_slabs_fmt", I, P, P, P, P, P, I, I, I, I, I, I, POINTER(WgrSeg), I, P)
     sig("nq_conv3_weight_bytes", L, I, I, I)
     sig("nq_weight_layout3", I, P, P, I, I, I, I, P)
     sig("nq_weight_layout3_multi", I, POINTER(WL3Seg), I, P)
@@ -162,7 +168,8 @@ EXPORTS = (
     "nq_conv_wgrad3_slabs", "nq_conv_wgrad3_swapped_slabs", "nq_conv_wgrad_slabs", "nq_wgrad_reduce_multi",
     "nq_conv_wgrad_ws_floats", "nq_conv_wgrad", "nq_ps_gelu_backward", "nq_tanh_out_backward", "nq_l2_loss",
     "nq_channel_sum", "nq_l2_loss_tanh_head", "nq_frame_sse", "nq_gather_frames_u8",
-    "nq_act_dd", "nq_pixel_shuffle", "nq_bias_add", "nq_head_forward_loss_ws_floats", "nq_head_forward_loss",
+    "nq_act_dd", "nq_pixel_shuffle", "nq_bias_add", "nq_conv3_split_io", "nq_conv_split_out", "nq_split_words",
+    "nq_conv_wgrad3_split_io", "nq_conv_wgrad3_fmt", "nq_conv_wgrad3_slabs_fmt", "nq_head_forward_loss_ws_floats", "nq_head_forward_loss",
     "nq_adaround_fwht_multi", "nq_fwht_adaround_adam_multi", "nq_weight_layouts_all",
 )
 

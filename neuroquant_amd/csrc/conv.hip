@@ -23,7 +23,8 @@ int nq_conv_splitk_finish(const float*, const float*, float*, float*, const floa
                           hipStream_t);
 int nq_head_supported(int, int);
 int nq_head_forward(const float*, const float*, int, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
-int nq_head_dgrad(const float*, const float*, int, const float*, float*, int, int, int, int, int, int, int, hipStream_t);
+int nq_head_dgrad(const float*, const float*, int, const float*, float*, int, int, int, int, int, int, int, int, hipStream_t);
+int nq_head_dgrad_streams(int, int, int, int, int, int, int, int);
 int nq_conv_wgrad_k1(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
                      int, hipStream_t);
 int nq_conv_wgrad_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int,
@@ -259,12 +260,25 @@ int64_t nq_conv_forward_ws_floats(int B, int Cin, int H, int W, int Cout, int k)
   return ns > 1 ? (int64_t)ns * B * Cout * H * W : 0;
 }
 
+// 1 when nq_conv_forward can write its output y as split {hi | lo} words for this call (include/nq_hip.h)
+int nq_conv_split_out(int B, int Cin, int H, int W, int Cout, int k, int r, int epilogue, int in_gelu, int has_bias) {
+  if (!ks_ok(k) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+  if (use_head_fwd(Cout, k, epilogue, in_gelu)) return 0;
+  if (!(nq_head_supported(Cin, k) && (epilogue == NQ_EPI_PLAIN || epilogue == NQ_EPI_DGRAD_GELU) && !in_gelu && !has_bias)) return 0;
+  return nq_head_dgrad_streams(B, Cout, H, W, Cin, k, epilogue == NQ_EPI_DGRAD_GELU ? r : 1, epilogue == NQ_EPI_DGRAD_GELU);
+}
+
 int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y, float* z, float* ws, int B, int Cin, int H,
                     int W, int Cout, int k, int krows, int ld, int r, int epilogue, int in_gelu, const float* zprev,
                     nq_stream_t stream) {
   if (!x || !wt || (!y && epilogue != NQ_EPI_PS) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0)
     return NQ_ERR_INVALID;
   if (!ks_ok(k)) return NQ_ERR_UNSUPPORTED;
+  // NQ_EPI_Y_SPLIT: the output as split {hi | lo} words -- only the streaming head data gradient offers it (nq_conv_split_out)
+  const int y_split = (epilogue & NQ_EPI_Y_SPLIT) ? 1 : 0;
+  if (epilogue & NQ_EPI_X_SPLIT) return NQ_ERR_UNSUPPORTED;
+  epilogue &= ~NQ_EPI_Y_SPLIT;
+  if (y_split && !nq_conv_split_out(B, Cin, H, W, Cout, k, r, epilogue, in_gelu, bias != nullptr)) return NQ_ERR_UNSUPPORTED;
   if (epilogue < 0 || epilogue > NQ_EPI_DGRAD_GELU) return NQ_ERR_INVALID;
   if ((epilogue == NQ_EPI_PS_GELU || epilogue == NQ_EPI_PS) && (!z || r <= 0 || Cout % (r * r) != 0)) return NQ_ERR_INVALID;
   if (epilogue == NQ_EPI_DGRAD_GELU && (!zprev || r <= 0 || H % r != 0 || W % r != 0)) return NQ_ERR_INVALID;
@@ -278,7 +292,7 @@ int nq_conv_forward(const float* x, const float* wt, const float* bias, float* y
     return nq_head_forward(x, wt, ld, bias, y, B, Cin, H, W, Cout, k, epilogue, st0);
   if (use_head_dgrad(Cin, k, epilogue, in_gelu, bias))
     return nq_head_dgrad(x, wt, ld, epilogue == NQ_EPI_DGRAD_GELU ? zprev : nullptr, y, B, Cout, H, W, Cin, k,
-                         epilogue == NQ_EPI_DGRAD_GELU ? r : 1, st0);
+                         epilogue == NQ_EPI_DGRAD_GELU ? r : 1, y_split, st0);
   // 1x1 convolutions over a handful of pixels (decoder stem / first block): compact thread-per-output kernel
   if (!in_gelu && nq_tiny_pw_supported(B, Cin, H, W, Cout, k))
     return nq_tiny_pw_forward(x, wt, bias, y, z, zprev, B, Cin, H, W, Cout, ld, r, epilogue, st0);

@@ -20,8 +20,8 @@ int nq_conv_flat3(const float*, const void*, const float*, float*, float*, const
                   int, int, int, int, hipStream_t);
 int nq_conv_wgrad_flat3_ok(int, int, int, int, int, int);
 int nq_conv_wgrad_flat3(const float*, const float*, float*, float*, int, int, int, int, int, int, hipStream_t);
-int nq_conv_wgrad3_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
-int nq_conv_wgrad3_k5(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+int nq_conv_wgrad3_k3(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
+int nq_conv_wgrad3_k5(const float*, const float*, float*, float*, int, int, int, int, int, int, int, int, int, int, int, int, hipStream_t);
 }
 
 namespace {
@@ -555,10 +555,24 @@ int nq_weight_layouts_all(const nq_wl3_seg* segs3, int n3, const nq_wl_seg* segs
   return nq_launch_status();
 }
 
+// Which sides of nq_conv_forward3 may travel as split {hi | lo} words for this shape: bit NQ_EPI_X_SPLIT -- the input (the tiled
+// kernel with >= 32-channel tiles stages it), bit NQ_EPI_Y_SPLIT -- the output y (the tiled kernel's own epilogue writes it: no
+// split-K).  0 for the few-pixel kernels and for shapes this path does not serve.
+int nq_conv3_split_io(int B, int Cin, int H, int W, int Cout, int k) {
+  if (!nq_conv3_supported(B, Cin, H, W, Cout, k)) return 0;
+  if (use_flat3(B, Cin, H, W, Cout, k, nullptr)) return 0;
+  const Fwd3Plan p = plan_fwd3(B, Cin, H, W, Cout);
+  return (p.mi >= 2 ? NQ_EPI_X_SPLIT : 0) | (p.nsplit == 1 ? NQ_EPI_Y_SPLIT : 0);
+}
+
 int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* y, float* z, const float* zprev, float* ws, int B,
                      int Cin, int H, int W, int Cout, int k, int r, int epilogue, nq_stream_t stream) {
   if (!x || !wt3 || (!y && epilogue != NQ_EPI_PS) || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
   if (!(k == 3 || k == 5)) return NQ_ERR_UNSUPPORTED;
+  // split {hi | lo} word interchange (include/nq_hip.h: NQ_EPI_X_SPLIT / NQ_EPI_Y_SPLIT): only where nq_conv3_split_io says so
+  const int fmt = epilogue & (NQ_EPI_X_SPLIT | NQ_EPI_Y_SPLIT);
+  epilogue &= ~(NQ_EPI_X_SPLIT | NQ_EPI_Y_SPLIT);
+  if (fmt & ~nq_conv3_split_io(B, Cin, H, W, Cout, k)) return NQ_ERR_UNSUPPORTED;
   if (epilogue < 0 || epilogue > NQ_EPI_DGRAD_GELU) return NQ_ERR_INVALID;
   if ((epilogue == NQ_EPI_PS_GELU || epilogue == NQ_EPI_PS) && (!z || r <= 0 || Cout % (r * r) != 0)) return NQ_ERR_INVALID;
   if (epilogue == NQ_EPI_DGRAD_GELU && (!zprev || r <= 0 || H % r != 0 || W % r != 0)) return NQ_ERR_INVALID;
@@ -577,8 +591,8 @@ int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* 
   }
   const Fwd3Plan p = plan_fwd3(B, Cin, H, W, Cout);
   if (p.nsplit > 1 && !ws) return NQ_ERR_INVALID;
-  int rc = (k == 3) ? nq_conv_igemm3_k3(x, wt3, bias, y, z, zprev, B, Cin, H, W, Cout, r, epilogue, p.mi, p.nsplit, p.per, ws, st)
-                    : nq_conv_igemm3_k5(x, wt3, bias, y, z, zprev, B, Cin, H, W, Cout, r, epilogue, p.mi, p.nsplit, p.per, ws, st);
+  int rc = (k == 3) ? nq_conv_igemm3_k3(x, wt3, bias, y, z, zprev, B, Cin, H, W, Cout, r, epilogue | fmt, p.mi, p.nsplit, p.per, ws, st)
+                    : nq_conv_igemm3_k5(x, wt3, bias, y, z, zprev, B, Cin, H, W, Cout, r, epilogue | fmt, p.mi, p.nsplit, p.per, ws, st);
   if (rc != NQ_OK || p.nsplit == 1) return rc;
   return nq_conv_splitk_finish(ws, bias, y, z, zprev, B, H, W, Cout, r, epilogue, p.nsplit, st);
 }
@@ -604,11 +618,29 @@ int64_t nq_conv_wgrad3_ws_floats(int B, int Cin, int H, int W, int Cout, int k) 
 }
 
 static int conv_wgrad3_impl(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W,
-                            int Cout, int k, int swap_kk, nq_wgr_seg* seg, nq_stream_t stream);
+                            int Cout, int k, int swap_kk, nq_wgr_seg* seg, nq_stream_t stream, int fmt = 0);
 
 int nq_conv_wgrad3(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
                    int k, nq_stream_t stream) {
   return conv_wgrad3_impl(x, dy, dw, db, ws, B, Cin, H, W, Cout, k, 0, nullptr, stream);
+}
+
+// Operands as split {hi | lo} words (include/nq_hip.h): fmt bit 0 -- x, bit 1 -- dy; where nq_conv_wgrad3_split_io says so
+int nq_conv_wgrad3_split_io(int B, int Cin, int H, int W, int Cout, int k) {
+  if (!nq_conv_wgrad3_supported(B, Cin, H, W, Cout, k) || nq_conv_wgrad_flat3_ok(B, Cin, H, W, Cout, k)) return 0;
+  const Wg3Plan p = plan_wgrad3(B, Cin, H, W, Cout, k);
+  return (p.pc == 1 || p.pc == 12 || p.pc == 14) ? 3 : 0;
+}
+int nq_conv_wgrad3_fmt(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W, int Cout,
+                       int k, int fmt, nq_stream_t stream) {
+  if (fmt & ~nq_conv_wgrad3_split_io(B, Cin, H, W, Cout, k)) return NQ_ERR_UNSUPPORTED;
+  return conv_wgrad3_impl(x, dy, dw, db, ws, B, Cin, H, W, Cout, k, 0, nullptr, stream, fmt);
+}
+int nq_conv_wgrad3_slabs_fmt(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W,
+                             int Cout, int k, nq_wgr_seg* seg, int fmt, nq_stream_t stream) {
+  if (!seg) return NQ_ERR_INVALID;
+  if (fmt & ~nq_conv_wgrad3_split_io(B, Cin, H, W, Cout, k)) return NQ_ERR_UNSUPPORTED;
+  return conv_wgrad3_impl(x, dy, dw, db, ws, B, Cin, H, W, Cout, k, 0, seg, stream, fmt);
 }
 
 int nq_conv_wgrad3_swapped(const float* x, const float* dy, float* dw, float* ws, int B, int Cin, int H, int W, int Cout, int k,
@@ -659,12 +691,13 @@ int nq_wgrad_reduce_multi(const nq_wgr_seg* segs, int nseg, nq_stream_t stream) 
 }
 
 static int conv_wgrad3_impl(const float* x, const float* dy, float* dw, float* db, float* ws, int B, int Cin, int H, int W,
-                            int Cout, int k, int swap_kk, nq_wgr_seg* seg, nq_stream_t stream) {
+                            int Cout, int k, int swap_kk, nq_wgr_seg* seg, nq_stream_t stream, int fmt) {
   if (!x || !dy || !dw || !ws || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0) return NQ_ERR_INVALID;
   if (!(k == 3 || k == 5)) return NQ_ERR_UNSUPPORTED;
   if ((int64_t)Cout * H * W >= (1ll << 31) || (int64_t)Cin * H * W >= (1ll << 31)) return NQ_ERR_UNSUPPORTED;
   if (swap_kk == 0 && nq_conv_wgrad_flat3_ok(B, Cin, H, W, Cout, k)) {
     // few-pixel layer: every output block is owned by one wave for the whole K range -- dw / db are final, nothing pending
+    if (fmt) return NQ_ERR_UNSUPPORTED;
     if (seg) *seg = nq_wgr_seg{nullptr, nullptr, dw, db, Cout, Cin * k * k, 0, 0, 0, 0, 1};
     return nq_conv_wgrad_flat3(x, dy, dw, db, B, Cin, H, W, Cout, k, nq_s(stream));
   }
@@ -672,8 +705,8 @@ static int conv_wgrad3_impl(const float* x, const float* dy, float* dw, float* d
   float* slab = ws;
   float* slab_db = ws + (int64_t)p.nsplit * p.co_pad * p.n_pad;
   hipStream_t st = nq_s(stream);
-  int rc = (k == 3) ? nq_conv_wgrad3_k3(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, p.pc, st)
-                    : nq_conv_wgrad3_k5(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, p.pc, st);
+  int rc = (k == 3) ? nq_conv_wgrad3_k3(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, p.pc, fmt, st)
+                    : nq_conv_wgrad3_k5(x, dy, slab, slab_db, B, Cin, H, W, Cout, p.co_pad, p.n_pad, p.nsplit, p.mi, p.ni, p.pc, fmt, st);
   if (rc != NQ_OK) return rc;
   const int N = Cin * k * k;
   int64_t total = (int64_t)Cout * N + Cout;

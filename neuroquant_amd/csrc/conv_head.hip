@@ -548,6 +548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((KS <= 3 &&
 struct HeadDg2Args {
   int B, Cin, H, W, ld, strips, rblocks;   // Cin = channels of the OUTPUT (naming of head_dgrad_kernel)
   unsigned dy_bytes, z_bytes;
+  int out_split;                           // the output is written as split {hi | lo} words (nq_common.h)
 };
 
 template <int R, int NCO>
@@ -652,7 +653,11 @@ __global__ __launch_bounds__(256) void head_dgrad2_kernel(const float* __restric
             acc1 = __builtin_elementwise_fma(w2, f32x2{in[kw + 2], in[kw + 3]}, acc1);
           }
       const f32x4 zz = z[r];
-      const f32x2 ev = {acc0[0] * zz[0], acc1[0] * zz[2]}, od = {acc0[1] * zz[1], acc1[1] * zz[3]};
+      f32x2 ev = {acc0[0] * zz[0], acc1[0] * zz[2]}, od = {acc0[1] * zz[1], acc1[1] * zz[3]};
+      if (a.out_split) {
+        ev = f32x2{nq_split_word_f(ev[0]), nq_split_word_f(ev[1])};
+        od = f32x2{nq_split_word_f(od[0]), nq_split_word_f(od[1])};
+      }
       const unsigned vo = oo[r];
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, ev), rs_o, vo, so, 0);
       __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, od), rs_o,
@@ -754,8 +759,18 @@ int nq_head_forward_loss(const float* x, const float* wt, int ld, const float* b
 }
 
 // dy (B,Cout,H,W) -> out = d/dx (B,Cin,H,W) [* gelu'(zprev)] stored PixelUnshuffle(r)-ed
+// 1 when nq_head_dgrad runs the streaming kernel for this call (the only one that can write split {hi | lo} words)
+int nq_head_dgrad_streams(int B, int Cin, int H, int W, int Cout, int k, int r, int has_z) {
+  const char* hv = getenv("NQ_HEAD_DGRAD");
+  const char* rd = getenv("NQ_HEAD_DG_R");
+  const int R = rd ? atoi(rd) : 4;
+  return k == 3 && Cout == 3 && r == 2 && has_z && (W % 4 == 0) && (H % 2 == 0) && (int64_t)B * Cin * H * W * 4 < 0xFFFFFF00ll &&
+         !(hv && hv[0] == '1') && (size_t)Cin * 28 * 4 <= 64 * 1024 && (R == 2 || R == 4);
+}
+
 int nq_head_dgrad(const float* dy, const float* wt, int ld, const float* zprev, float* out, int B, int Cin, int H, int W,
-                  int Cout, int k, int r, hipStream_t st) {
+                  int Cout, int k, int r, int out_split, hipStream_t st) {
+  if (out_split && !nq_head_dgrad_streams(B, Cin, H, W, Cout, k, r, zprev != nullptr)) return NQ_ERR_UNSUPPORTED;
   // the shipped head (3x3, 3 image channels, GELU + PixelShuffle(2) below it): the streaming kernel; 32-bit buffer offsets
   const char* hv = getenv("NQ_HEAD_DGRAD");   // NQ_HEAD_DGRAD=1: the LDS-staged kernel (A/B runs; read per call)
   if (k == 3 && Cout == 3 && r == 2 && zprev && (W % 4 == 0) && (H % 2 == 0) && (int64_t)B * Cin * H * W * 4 < 0xFFFFFF00ll &&
@@ -767,6 +782,7 @@ int nq_head_dgrad(const float* dy, const float* wt, int ld, const float* zprev, 
     a.strips = (W + 255) / 256; a.rblocks = (H + R - 1) / R;
     a.dy_bytes = (unsigned)((int64_t)B * Cout * H * W * 4);
     a.z_bytes = (unsigned)((int64_t)B * Cin * H * W * 4);
+    a.out_split = out_split;
     const int waves = B * a.strips * a.rblocks;
     dim3 g2((unsigned)((waves + 3) / 4)), blk2(256);
     const size_t lds = (size_t)Cin * 28 * 4;

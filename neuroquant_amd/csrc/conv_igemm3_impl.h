@@ -50,6 +50,7 @@ struct Conv3Args {
   int nsplit, per_split;  // split-K over channel chunks: blockIdx.z = b*nsplit + split, chunks [split*per, +per)
   float* slab;            // [nsplit][B][Cout][H][W] raw partial sums when nsplit > 1 (nq_conv_splitk_finish adds them)
   int lds_epi;            // the launch reserved MT*1024 B of LDS: the data-gradient epilogue may transpose through it
+  int y_split;            // y is written as split {hi | lo} words (nq_common.h) instead of floats; x: template parameter XS
   unsigned w_bytes;       // size of the wt3 operand (buffer resource range)
   int tail;               // shape of the LAST 16-channel chunk, by the channels r it really holds (no MFMAs on all-zero k-values):
                           //   0: r > 12   NST   k-steps of (2 octets x 2 taps)                                  13 for k = 5
@@ -126,7 +127,8 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 // between a prologue and an epilogue of global-memory latency -- bound by latency, not by issue slots; tools/bench_nerv_tail.py).
 // With the weights travelling by LDS-DMA the 48-channel tile holds 167 VGPRs and 48.5 KB of LDS: three workgroups per CU
 // (with two weight register sets it needed 264 B of scratch for that: 132 -> 202 us).
-template <int MI, int WPE = 2>
+// XS: the input x holds split {hi | lo} words (written by a producer with y_split): staging re-packs halves, no conversion.
+template <int MI, int WPE = 2, bool XS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void conv_igemm3_kernel(Conv3Args a) {
   constexpr int MT = 16 * MI;
   constexpr int W_U4 = 2 * 4 * MT;            // 16-byte units per weight buffer: [plane][kq][MT]
@@ -234,7 +236,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       if (4 * QP == PW || 4 * it_q + e_ < PW) {                                                       \
         const float c_[8] = {pv[0][e_], pv[1][e_], pv[2][e_], pv[3][e_], pv[4][e_], pv[5][e_], pv[6][e_], pv[7][e_]}; \
         u32x4 hi_, lo_;                                                                               \
-        split8(c_, hi_, lo_);                                                                         \
+        if constexpr (XS) {                                                                           \
+          _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                          \
+            const unsigned w0_ = __builtin_bit_cast(unsigned, c_[2 * j_]), w1_ = __builtin_bit_cast(unsigned, c_[2 * j_ + 1]); \
+            hi_[j_] = __builtin_amdgcn_perm(w1_, w0_, 0x07060302u);                                   \
+            lo_[j_] = __builtin_amdgcn_perm(w1_, w0_, 0x05040100u);                                   \
+          }                                                                                           \
+        } else {                                                                                      \
+          split8(c_, hi_, lo_);                                                                       \
+        }                                                                                             \
         (DST)[it_oct * PP + it_r * PW + 4 * it_q + e_] = hi_;                                         \
         (DST)[2 * PP + it_oct * PP + it_r * PW + 4 * it_q + e_] = lo_;                                \
       }                                                                                               \
@@ -598,6 +608,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
       const int64_t cbase = ((int64_t)b * Cout + cc) * HW;
       const f32x4 d4 = *reinterpret_cast<const f32x4*>(a.zprev + cbase + (int64_t)py * W + px0);
       v = v * d4;
+      if (a.y_split) v = f32x4{nq_split_word_f(v[0]), nq_split_word_f(v[1]), nq_split_word_f(v[2]), nq_split_word_f(v[3])};
       float* __restrict__ yo = a.y + cbase;
       if (r == 2) {
         const int o = ((py & 1) * 2) * plane + (py >> 1) * Wo + (px0 >> 1);
@@ -644,7 +655,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         float* __restrict__ yo = a.y + cbase;
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb)
-          if (in_off[nb] >= 0) yo[out_off[nb]] = (acc[mi][nb][reg] + bv) * zp[in_off[nb]];
+          if (in_off[nb] >= 0) {
+            const float v = (acc[mi][nb][reg] + bv) * zp[in_off[nb]];
+            yo[out_off[nb]] = a.y_split ? nq_split_word_f(v) : v;
+          }
       }
     });
     return;
@@ -675,6 +689,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, d0 = v0, d1 = v1, d2 = v2, d3 = v3;  // PS: z = conv; PS_GELU: z = gelu'
         if (want_act) {
           nq_gelu_pair(v0, g0, d0); nq_gelu_pair(v1, g1, d1); nq_gelu_pair(v2, g2, d2); nq_gelu_pair(v3, g3, d3);
+          if (a.y_split) { g0 = nq_split_word_f(g0); g1 = nq_split_word_f(g1); g2 = nq_split_word_f(g2); g3 = nq_split_word_f(g3); }
         }
         const int64_t o = (((int64_t)b * C + (co >> 2)) * (2 * H) + 2 * py + (odd ? 1 : 0)) * W2 + 2 * (px - (odd ? 1 : 0));
         {
@@ -710,6 +725,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         float g0, g1, g2, g3, d0 = v0, d1 = v1, d2 = v2, d3 = v3;  // PS: z = conv; PS_GELU: z = gelu'(conv)
         if (want_act) {
           nq_gelu_pair(v0, g0, d0); nq_gelu_pair(v1, g1, d1); nq_gelu_pair(v2, g2, d2); nq_gelu_pair(v3, g3, d3);
+          if (a.y_split) { g0 = nq_split_word_f(g0); g1 = nq_split_word_f(g1); g2 = nq_split_word_f(g2); g3 = nq_split_word_f(g3); }
         }
         if (r == 2) {
           const int64_t o0 = rowbase + (int64_t)px * 2, o1 = o0 + (int64_t)W * 2;
@@ -737,21 +753,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
           if (epi == NQ_EPI_PS_GELU) {
             float gv, dv;
             nq_gelu_pair(v, gv, dv);
-            a.y[o] = gv;
+            a.y[o] = a.y_split ? nq_split_word_f(gv) : gv;
             a.z[o] = dv;
           } else {
             a.z[o] = v;
           }
         } else {
           const int64_t o = ((int64_t)b * Cout + cc) * HW + (int64_t)py * W + px;
-          a.y[o] = (epi == NQ_EPI_TANH) ? tanhf(v) * 0.5f + 0.5f : v;
+          const float ov = (epi == NQ_EPI_TANH) ? tanhf(v) * 0.5f + 0.5f : v;
+          a.y[o] = a.y_split ? nq_split_word_f(ov) : ov;
         }
       }
     }
   });
 }
 
-template <int MI>
+template <int MI, bool XS = false>
 int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
   constexpr int MT = 16 * MI;
   size_t lds = (size_t)(PATCH_U4 + 2 * 2 * 4 * MT) * 16;   // patch + two weight buffers (register-staged tiles)
@@ -768,13 +785,13 @@ int launch_igemm3(const Conv3Args& a_in, int tiles, hipStream_t st) {
     static const int occ3_steps = [] { const char* e = getenv("NQ_IG3_OCC3_STEPS"); return e ? atoi(e) : NQ_IG3_OCC3_DEFAULT; }();
     const int ksteps = (a.nsplit > 1 ? a.per_split : a.nchunk - 1) * NST + (a.nsplit > 1 ? 0 : nst_of_kind(a.tail));
     if (ksteps <= occ3_steps) {
-      if (int rc = nq_lds_optin<&conv_igemm3_kernel<MI, 3>>(lds)) return rc;
-      hipLaunchKernelGGL((conv_igemm3_kernel<MI, 3>), dim3((unsigned)(tiles * a.co_tiles * a.B * a.nsplit)), dim3(256), lds, st, a);
+      if (int rc = nq_lds_optin<&conv_igemm3_kernel<MI, 3, XS>>(lds)) return rc;
+      hipLaunchKernelGGL((conv_igemm3_kernel<MI, 3, XS>), dim3((unsigned)(tiles * a.co_tiles * a.B * a.nsplit)), dim3(256), lds, st, a);
       return nq_launch_status();
     }
   }
-  if (int rc = nq_lds_optin<&conv_igemm3_kernel<MI>>(lds)) return rc;
-  hipLaunchKernelGGL(conv_igemm3_kernel<MI>, dim3((unsigned)(tiles * a.co_tiles * a.B * a.nsplit)), dim3(256), lds, st, a);
+  if (int rc = nq_lds_optin<&conv_igemm3_kernel<MI, 2, XS>>(lds)) return rc;
+  hipLaunchKernelGGL((conv_igemm3_kernel<MI, 2, XS>), dim3((unsigned)(tiles * a.co_tiles * a.B * a.nsplit)), dim3(256), lds, st, a);
   return nq_launch_status();
 }
 
@@ -790,6 +807,11 @@ extern "C" int NQ_CAT(nq_conv_igemm3_k, NQ_KS)(const float* x, const void* wt3, 
   Conv3Args a;
   a.nsplit = nsplit; a.per_split = per_split; a.slab = slab;
   a.x = x; a.wt3 = wt3; a.bias = bias; a.y = y; a.z = z; a.zprev = zprev;
+  // bits 8 / 9 of `epi`: x holds / y is written as split {hi | lo} words (NQ_EPI_X_SPLIT / NQ_EPI_Y_SPLIT, include/nq_hip.h)
+  const bool xs = (epi & 0x100) != 0;
+  a.y_split = (epi & 0x200) ? 1 : 0;
+  epi &= 0xFF;
+  if (a.y_split && nsplit > 1) return NQ_ERR_UNSUPPORTED;   // (the slabs are finished by another kernel)
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.r = r; a.epi = epi;
   a.tiles_x = (W + TW - 1) / TW;
   a.nchunk = (Cin + CC - 1) / CC;
@@ -797,6 +819,15 @@ extern "C" int NQ_CAT(nq_conv_igemm3_k, NQ_KS)(const float* x, const void* wt3, 
   a.co_tiles = (Cout + 16 * mi_sel - 1) / (16 * mi_sel);
   a.w_bytes = (unsigned)(((int64_t)(a.nchunk - 1) * NST + nst_of_kind(a.tail)) * 2 * a.co_tiles * 4 * (16 * mi_sel) * 16);
   const int tiles = a.tiles_x * ((H + TH - 1) / TH);
+  if (xs) {   // (the 16-channel tile is not offered with split input: no layer of the shipped models pairs them)
+    switch (mi_sel) {
+      case 2: return launch_igemm3<2, true>(a, tiles, st);
+      case 3: return launch_igemm3<3, true>(a, tiles, st);
+      case 4: return launch_igemm3<4, true>(a, tiles, st);
+      case 5: return launch_igemm3<5, true>(a, tiles, st);
+      default: return NQ_ERR_UNSUPPORTED;
+    }
+  }
   switch (mi_sel) {
     case 1: return launch_igemm3<1>(a, tiles, st);
     case 2: return launch_igemm3<2>(a, tiles, st);

@@ -35,6 +35,7 @@ struct Wgrad3Args {
   float* slab;     // [nsplit][co_pad][n_pad]
   float* slab_db;  // [nsplit][co_pad]
   int B, Cin, H, W, Cout, N, co_pad, n_pad, segs_x, nseg, nsplit;
+  int x_split, dy_split;   // producer/consumer kernel: x / dy hold split {hi | lo} words (nq_common.h) instead of floats
 };
 
 // Timing experiments only (never in the product build): -DNQ_WG3_ABL=n compiles conv_wgrad3p_kernel WITHOUT one of its
@@ -546,6 +547,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NI == 1 ? 4
           u32x4* const dst = dz + it.sub * SUBS + kqd * MT + (it.co ^ ((kqd & 2) << 1));
           u32x4 hi, lo;
           float s = 0.f;
+          if (a.dy_split) {
+            // the values are {hi | lo} words already: two v_perm_b32 per pixel pair; the bias gradient sums hi + lo (what the
+            // matrix pipe sees of dY) with one packed dot product per half, only in the workgroups that own it
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const unsigned w0 = __builtin_bit_cast(unsigned, (j < 2) ? dv[i][0][2 * j] : dv[i][1][2 * j - 4]);
+              const unsigned w1 = __builtin_bit_cast(unsigned, (j < 2) ? dv[i][0][2 * j + 1] : dv[i][1][2 * j - 3]);
+              hi[j] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);
+              lo[j] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);
+            }
+            if (do_db) {
+              const bf16x2_t one = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                // (through named scalars: __builtin_bit_cast applied directly to a vector element reads element 0 with hipcc 7.2)
+                const unsigned hj = hi[j], lj = lo[j];
+                s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, hj), one, s, false);
+                s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, lj), one, s, false);
+              }
+            }
+          } else {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const float f0 = (j < 2) ? dv[i][0][2 * j] : dv[i][1][2 * j - 4];
@@ -554,6 +576,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NI == 1 ? 4
             const unsigned h2 = pk_bf16(f0, f1);
             hi[j] = h2;
             lo[j] = pk_bf16(f0 - lo_as_f32(h2), f1 - hi_as_f32(h2));
+          }
           }
           db_part[i] += s;
           dst[0] = hi;
@@ -568,10 +591,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NI == 1 ? 4
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) {
             const float f0 = xv[i][2 * jp], f1 = xv[i][2 * jp + 1];
-            const unsigned h2 = pk_bf16(f0, f1);
-            const unsigned l2 = pk_bf16(f0 - lo_as_f32(h2), f1 - hi_as_f32(h2));
-            const unsigned w0 = __builtin_amdgcn_perm(h2, l2, 0x05040100u);
-            const unsigned w1 = __builtin_amdgcn_perm(h2, l2, 0x07060302u);
+            unsigned w0, w1;
+            if (a.x_split) {   // already the {hi | lo} word this image holds per pixel
+              w0 = __builtin_bit_cast(unsigned, f0);
+              w1 = __builtin_bit_cast(unsigned, f1);
+            } else {
+              const unsigned h2 = pk_bf16(f0, f1);
+              const unsigned l2 = pk_bf16(f0 - lo_as_f32(h2), f1 - hi_as_f32(h2));
+              w0 = __builtin_amdgcn_perm(h2, l2, 0x05040100u);
+              w1 = __builtin_amdgcn_perm(h2, l2, 0x07060302u);
+            }
             if constexpr (4 * Q == RW) {
               d[2 * jp] = w0;
               d[2 * jp + 1] = w1;
@@ -771,8 +800,10 @@ int launch_wgrad3(const Wgrad3Args& a, hipStream_t st) {
 // or 1 for C_in*k*k <= 64)
 extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, float* slab, float* slab_db, int B, int Cin,
                                                 int H, int W, int Cout, int co_pad, int n_pad, int nsplit, int mi_sel,
-                                                int ni_sel, int pc, hipStream_t st) {
+                                                int ni_sel, int pc, int fmt, hipStream_t st) {
   Wgrad3Args a;
+  a.x_split = fmt & 1; a.dy_split = (fmt >> 1) & 1;   // split {hi | lo} word operands: the row-segment producer/consumer variants only
+  if (fmt && !(pc == 1 || pc == 12 || pc == 14)) return NQ_ERR_UNSUPPORTED;
   a.x = x; a.dy = dy; a.slab = slab; a.slab_db = slab_db;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.N = Cin * KK;
   a.co_pad = co_pad; a.n_pad = n_pad;

@@ -235,6 +235,12 @@ __global__ __launch_bounds__(TPB) void bias_add_kernel(const float* __restrict__
   y[e] = (x ? x[e] : 0.f) + bias[c];
 }
 
+// float -> split {hi | lo} word (nq_common.h), elementwise: for callers that hand a bf16x3 kernel a pre-split operand
+__global__ __launch_bounds__(256) void split_words_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = nq_split_word_f(x[i]);
+}
+
 }  // namespace
 
 extern "C" {
@@ -250,6 +256,13 @@ int nq_pixel_shuffle(const float* x, float* y, int B, int C, int H, int W, int r
   const int64_t n = (int64_t)B * C * r * r * H * W;
   hipLaunchKernelGGL(pixel_shuffle_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, nq_s(stream), x, y, C, H, W, r,
                      inverse ? 1 : 0, n);
+  return nq_launch_status();
+}
+
+int nq_split_words(const float* x, float* y, int64_t n, nq_stream_t stream) {
+  if (!x || !y || n < 0) return NQ_ERR_INVALID;
+  if (n == 0) return NQ_OK;
+  hipLaunchKernelGGL(split_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nq_s(stream), x, y, n);
   return nq_launch_status();
 }
 

@@ -68,6 +68,22 @@ __device__ __forceinline__ void nq_gelu_pair(float v, float& g, float& dg) {
   dg = __builtin_fmaf(v, 0.39894228040143267794f * e, cdf);
 }
 
+// ---- split ("hi | lo") words: the interchange format of activations / gradients between the bf16x3 kernels (round 4) ----
+// A float v travels as ONE 32-bit word {bf16 hi in the upper half, bf16 lo in the lower half}, hi = bf16(v), lo = bf16(v - hi),
+// both round-to-nearest-even: exactly the two operands the bf16x3 kernels derive from v when they stage it (split8 in
+// conv_igemm3_impl.h, split_word in conv_wgrad3_impl.h), so a consumer that receives the word only re-packs halves (one
+// v_perm_b32 per pair) instead of converting (two conversions + a subtraction per value).  Same bytes per element as fp32.
+__device__ __forceinline__ unsigned nq_split_word_u(float v) {
+  const __bf16 h = (__bf16)v;
+  const __bf16 l = (__bf16)(v - (float)h);
+  return ((unsigned)__builtin_bit_cast(unsigned short, h) << 16) | (unsigned)__builtin_bit_cast(unsigned short, l);
+}
+__device__ __forceinline__ float nq_split_word_f(float v) { return __builtin_bit_cast(float, nq_split_word_u(v)); }
+// value a split word stands for: hi + lo (what the matrix pipe sees of v)
+__device__ __forceinline__ float nq_split_word_value(unsigned w) {
+  return __builtin_bit_cast(float, w & 0xffff0000u) + __builtin_bit_cast(float, w << 16);
+}
+
 // ---- wave / block reductions (wave = 64 lanes) ----
 __device__ __forceinline__ float nq_wave_sum(float v) {
 #pragma unroll

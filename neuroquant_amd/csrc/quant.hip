@@ -507,7 +507,7 @@ inline bool bad_rows(int64_t rows, int64_t row_len) {
 
 extern "C" {
 
-int nq_abi_version(void) { return 4; }
+int nq_abi_version(void) { return 5; }
 
 const char* nq_error_string(int code) {
   switch (code) {

@@ -31,6 +31,8 @@ def _q(name, *args):
 
 EPI_PLAIN, EPI_PS_GELU, EPI_TANH, EPI_PS, EPI_DGRAD_GELU = (L.EPI_PLAIN, L.EPI_PS_GELU, L.EPI_TANH, L.EPI_PS,
                                                                 L.EPI_DGRAD_GELU)
+# split {hi | lo} word interchange between the bf16x3 kernels (include/nq_hip.h: NQ_EPI_X_SPLIT / NQ_EPI_Y_SPLIT)
+EPI_X_SPLIT, EPI_Y_SPLIT = 0x100, 0x200
 
 
 def _stream():
@@ -594,9 +596,10 @@ def weight_layouts_all(items3, items_f):
     return outs3, outsf
 
 
-def conv_forward_raw(x, wt, dims, bias, cout, k, epilogue, r, in_gelu=False, zprev=None):
+def conv_forward_raw(x, wt, dims, bias, cout, k, epilogue, r, in_gelu=False, zprev=None, fmt=0):
     """One nq_conv_forward launch.  Returns (y, z): z = shuffled pre-activation for the PixelShuffle epilogues
-    (y is None for EPI_PS), y = un-shuffled gradient for EPI_DGRAD_GELU."""
+    (y is None for EPI_PS), y = un-shuffled gradient for EPI_DGRAD_GELU.  fmt = EPI_Y_SPLIT: y as split {hi | lo} words
+    (conv_split_out says where)."""
     B, cin, H, W = x.shape
     y = z = None
     if epilogue in (EPI_PS_GELU, EPI_PS):
@@ -611,13 +614,36 @@ def conv_forward_raw(x, wt, dims, bias, cout, k, epilogue, r, in_gelu=False, zpr
     ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
     _timed(("conv_igemm", k, cin, cout, H, W, B, epilogue),
            lambda: L.check(L.lib().nq_conv_forward(_p(x), _p(wt), _p(bias), _p(y), _p(z), _p(ws), B, cin, H, W, cout, k,
-                                                   dims[0], dims[1], r, epilogue, 1 if in_gelu else 0, _p(zprev),
+                                                   dims[0], dims[1], r, epilogue | fmt, 1 if in_gelu else 0, _p(zprev),
                                                    _stream()), "conv_forward"))
     return y, z
 
 
 def conv3_supported(B, cin, H, W, cout, k):
     return bool(_q("nq_conv3_supported", B, cin, H, W, cout, k))
+
+
+def conv3_split_io(B, cin, H, W, cout, k):
+    """EPI_X_SPLIT | EPI_Y_SPLIT bits: the sides of conv3_forward_raw that may travel as split {hi | lo} words for this shape"""
+    return int(_q("nq_conv3_split_io", B, cin, H, W, cout, k))
+
+
+def conv_wgrad3_split_io(B, cin, H, W, cout, k):
+    """bit 0: x, bit 1: dy of conv_wgrad3_raw may be split words for this shape"""
+    return int(_q("nq_conv_wgrad3_split_io", B, cin, H, W, cout, k))
+
+
+def conv_split_out(B, cin, H, W, cout, k, r, epilogue, has_bias=False):
+    """True when conv_forward_raw can write y as split words for this call (the streaming head data gradient)"""
+    return bool(_q("nq_conv_split_out", B, cin, H, W, cout, k, r, epilogue, 0, 1 if has_bias else 0))
+
+
+def split_words(x):
+    """float tensor -> the same shape holding split {hi | lo} words (bit patterns in a float32 tensor)"""
+    x = _dev(x).contiguous()
+    y = torch.empty_like(x)
+    L.check(L.lib().nq_split_words(_p(x), _p(y), x.numel(), _stream()), "split_words")
+    return y
 
 
 def weight_layout3(w, transposed=False):
@@ -646,8 +672,9 @@ def weight_layout3_multi(items):
     return outs
 
 
-def conv3_forward_raw(x, wt3, bias, cout, k, epilogue, r, zprev=None):
-    """bf16x3 counterpart of conv_forward_raw (same outputs)."""
+def conv3_forward_raw(x, wt3, bias, cout, k, epilogue, r, zprev=None, fmt=0):
+    """bf16x3 counterpart of conv_forward_raw (same outputs).  fmt: EPI_X_SPLIT (x holds split words) | EPI_Y_SPLIT (y is
+    written as split words), where conv3_split_io allows."""
     B, cin, H, W = x.shape
     y = z = None
     if epilogue in (EPI_PS_GELU, EPI_PS):
@@ -662,7 +689,7 @@ def conv3_forward_raw(x, wt3, bias, cout, k, epilogue, r, zprev=None):
     ws = torch.empty(nws, device=x.device, dtype=torch.float32) if nws else None
     _timed(("conv_igemm3", k, cin, cout, H, W, B, epilogue),
            lambda: L.check(L.lib().nq_conv_forward3(_p(x), _p(wt3), _p(bias), _p(y), _p(z), _p(zprev), _p(ws), B, cin, H, W,
-                                                    cout, k, r, epilogue, _stream()), "conv_forward3"))
+                                                    cout, k, r, epilogue | fmt, _stream()), "conv_forward3"))
     return y, z
 
 
@@ -688,10 +715,10 @@ class PendingReductions:
         self.segs, self.keep = [], []
 
 
-def conv_wgrad3_raw(x, dy, cout, k, want_db, out=None, defer=None):
+def conv_wgrad3_raw(x, dy, cout, k, want_db, out=None, defer=None, fmt=0):
     """bf16x3 counterpart of conv_wgrad_raw.  out = (dw, db) pre-allocated contiguous outputs (views of a flat
     gradient arena) or None.  defer (PendingReductions): only the split kernel runs now, dw / db are valid after
-    defer.flush()."""
+    defer.flush().  fmt bit 0 / 1: x / dy hold split {hi | lo} words (conv_wgrad3_split_io)."""
     B, cin, H, W = x.shape
     ws = torch.empty(_q("nq_conv_wgrad3_ws_floats", B, cin, H, W, cout, k), device=x.device, dtype=torch.float32)
     dw = torch.empty((cout, cin, k, k), device=x.device, dtype=torch.float32) if out is None else out[0]
@@ -699,13 +726,13 @@ def conv_wgrad3_raw(x, dy, cout, k, want_db, out=None, defer=None):
     if defer is not None:
         seg = L.WgrSeg()
         _timed(("conv_wgrad3", k, cin, cout, H, W, B, 0),
-               lambda: L.check(L.lib().nq_conv_wgrad3_slabs(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k,
-                                                            ctypes.byref(seg), _stream()), "conv_wgrad3_slabs"))
+               lambda: L.check(L.lib().nq_conv_wgrad3_slabs_fmt(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k,
+                                                                ctypes.byref(seg), fmt, _stream()), "conv_wgrad3_slabs"))
         defer.add(seg, ws, dw, db)
         return dw, db
     _timed(("conv_wgrad3", k, cin, cout, H, W, B, 0),
-           lambda: L.check(L.lib().nq_conv_wgrad3(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k, _stream()),
-                           "conv_wgrad3"))
+           lambda: L.check(L.lib().nq_conv_wgrad3_fmt(_p(x), _p(dy), _p(dw), _p(db), _p(ws), B, cin, H, W, cout, k, fmt,
+                                                      _stream()), "conv_wgrad3"))
     return dw, db
 
 
@@ -1239,6 +1266,7 @@ class _DecoderStackFn(Function):
         # pre-split operands are then built by ONE launch before the first convolution
         Bx, Hx, Wx = x.shape[0], x.shape[2], x.shape[3]
         plan, items = [], []
+        fio, bio, wio = [0] * n, [0] * n, [0] * n   # split {hi | lo} word capabilities: forward / data gradient / weight gradient
         for l, (k, r, act) in enumerate(spec.layers):
             W = _dev(wb[2 * l], "weight")
             cout, cin = W.shape[0], W.shape[1]
@@ -1247,11 +1275,31 @@ class _DecoderStackFn(Function):
             plan.append((use3, use3_bwd, len(items) if use3 else -1, len(items) + int(use3) if use3_bwd else -1))
             if use3:
                 items.append((W, False))
+                fio[l] = conv3_split_io(Bx, cin, Hx, Wx, cout, k)
             if use3_bwd:
                 items.append((W, True))
+                bio[l] = conv3_split_io(Bx, cout, Hx, Wx, cin, k)
+            if spec.precision == "bf16x3" and conv_wgrad3_supported(Bx, cin, Hx, Wx, cout, k):
+                wio[l] = conv_wgrad3_split_io(Bx, cin, Hx, Wx, cout, k)
+            if l == n - 1 and l > 0 and not use3_bwd:   # the head's data gradient (streaming vector kernel) can write split words
+                kp, rp, actp = spec.layers[l - 1]
+                if actp and conv_split_out(Bx, cout, Hx, Wx, cin, k, rp, EPI_DGRAD_GELU):
+                    bio[l] = EPI_Y_SPLIT
             if l == 0:
                 Hx, Wx = Hx * spec.fc_hw[0], Wx * spec.fc_hw[1]
             Hx, Wx = Hx * r, Wx * r
+        # Which tensors travel as split {hi | lo} words (round 4; NQ_SPLIT_IO=0: none): the input x_l of layer l (l >= 2: written by
+        # the GELU epilogue of layer l - 1, read by layer l's forward patch staging and by its weight gradient) and the conv-output
+        # gradient g_l (written by the data gradient of layer l + 1, read by layer l's weight gradient and data gradient) --
+        # where EVERY kernel on both sides takes / writes that form.  Same values in the matrix pipe: identical results.
+        split_on = spec.precision == "bf16x3" and os.environ.get("NQ_SPLIT_IO", "1") != "0"
+        xsp, gsp = [False] * n, [False] * n
+        if split_on:
+            for l in range(2, n):
+                xsp[l] = bool(spec.layers[l - 1][2] and (fio[l - 1] & EPI_Y_SPLIT) and (fio[l] & EPI_X_SPLIT) and (wio[l] & 1))
+            for l in range(1, n - 1):
+                gsp[l] = bool((bio[l + 1] & EPI_Y_SPLIT) and (bio[l] & EPI_X_SPLIT) and (wio[l] & 2) and spec.layers[l - 1][2]
+                              and not (l == 1 and spec.fc_hw != (1, 1)))
         # the fp32 operands (layers / directions that stay on the fp32 kernels) come from the SAME launch (round 4).
         # layer 0's data-gradient operand is only needed when the embedding itself is trained (FP32 trainer: the
         # ConvNeXt encoder sits below it, reference regress.py:259-266)
@@ -1289,12 +1337,14 @@ class _DecoderStackFn(Function):
             if fused_loss is not None:
                 y, z = fused_loss[0], None
             elif use3:
-                y, z = conv3_forward_raw(x, wt3, b, cout, k, epi, r)
+                y, z = conv3_forward_raw(x, wt3, b, cout, k, epi, r,
+                                         fmt=(EPI_X_SPLIT if xsp[l] else 0) | (EPI_Y_SPLIT if l + 1 < n and xsp[l + 1] else 0))
             else:
                 y, z = conv_forward_raw(x, wt, dims, b, cout, k, epi, r, in_gelu=in_gelu)
             saved_in.append(x)
             saved_z.append(zprev)
-            metas.append((k, r, act, cout, cin, in_gelu, wbk, dims_b, b is not None, operands[i_b] if use3_bwd else None))
+            metas.append((k, r, act, cout, cin, in_gelu, wbk, dims_b, b is not None, operands[i_b] if use3_bwd else None,
+                          xsp[l], gsp[l]))
             if epi == EPI_PS_GELU:
                 x, zprev, in_gelu = y, z, False
             elif epi == EPI_PS:
@@ -1393,12 +1443,13 @@ def _decoder_backward_steps(ctx, g_img):
     pending = PendingReductions() if side is None and os.environ.get("NQ_DEFER_REDUCE", "1") != "0" else None
 
     def wgrad(l, dconv):
-        k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
+        k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3, x_split, g_split = metas[l]
         x_in = xs[l]
         Bx, _, Hx, Wx = x_in.shape
         out = views[l] if views is not None else None
         if spec.precision == "bf16x3" and not in_gelu and conv_wgrad3_supported(Bx, cin, Hx, Wx, cout, k):
-            return conv_wgrad3_raw(x_in, dconv, cout, k, has_b, out=out, defer=pending)
+            return conv_wgrad3_raw(x_in, dconv, cout, k, has_b, out=out, defer=pending,
+                                   fmt=(1 if x_split else 0) | (2 if g_split else 0))
         if spec.precision == "bf16x3" and not in_gelu and cout <= 4 and cin > 4 and cout * k * k <= 64 \
                 and conv_wgrad3_supported(Bx, cout, Hx, Wx, cin, k):
             if l == n - 1 and has_b and head_db is not None:   # bias gradient handed over by l2_loss_head_grad
@@ -1412,22 +1463,23 @@ def _decoder_backward_steps(ctx, g_img):
 
     def dgrad(l, dconv):
         """conv-output gradient of layer l -> conv-output gradient of layer l - 1 (l >= 1)"""
-        k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[l]
+        k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3, x_split, g_split = metas[l]
         kp, rp, actp = spec.layers[l - 1]
         epi_b, r_b, zp = (EPI_DGRAD_GELU, rp, zs[l]) if actp else (EPI_PLAIN, 1, None)
         if not actp and rp != 1:
             raise NotImplementedError("PixelShuffle without activation between decoder layers")
+        out_split = EPI_Y_SPLIT if metas[l - 1][11] else 0   # the gradient this call produces is layer l - 1's g
         # the layer below ends in GELU: d(pre-activation) = dgrad * gelu'(z), stored as ITS conv-output gradient
-        if W3 is not None:
-            d, _ = conv3_forward_raw(dconv, W3, None, cin, k, epi_b, r_b, zprev=zp)   # W3 = pre-built transposed operand
+        if W3 is not None:   # W3 = pre-built transposed operand
+            d, _ = conv3_forward_raw(dconv, W3, None, cin, k, epi_b, r_b, zprev=zp, fmt=(EPI_X_SPLIT if g_split else 0) | out_split)
         else:
-            d, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, epi_b, r_b, zprev=zp)
+            d, _ = conv_forward_raw(dconv, wbk, dims_b, None, cin, k, epi_b, r_b, zprev=zp, fmt=out_split)
         if not actp and l == 1 and spec.fc_hw != (1, 1):
             d = _channels_from_space(d, *spec.fc_hw).contiguous()
         return d
 
     def emb_grad(dconv):   # d(embedding): plain data gradient through layer 0 (no activation below it)
-        k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[0]
+        k, r, act, cout, cin, in_gelu, wbk, dims_b, has_b, W3 = metas[0][:10]
         return conv_forward_raw(dconv, wbk, dims_b, None, cin, k, EPI_PLAIN, 1)[0]
 
     if arena is not None and arena_two_phase and n > 1:

@@ -20,7 +20,7 @@ def test_header_symbols_exported():
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in nq_hip.h but not exported"
     assert declared == set(_lib.EXPORTS)
-    assert lib.nq_abi_version() == 4 == _lib.ABI_VERSION
+    assert lib.nq_abi_version() == 5 == _lib.ABI_VERSION
     assert lib.nq_error_string(-1) == b"invalid argument"
     # ... and nothing else: the library is built with -fvisibility=hidden, only NQ_API declarations are dynamic symbols
     import shutil

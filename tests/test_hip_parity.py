@@ -330,6 +330,81 @@ def test_wgrad_bf16x3(ops, case):
     assert torch.equal(dw, dw2) and torch.equal(db, db2)
 
 
+def _split_words_host(x):
+    """numpy restatement of nq_common.h::nq_split_word_u: {bf16(v) << 16 | bf16(v - bf16(v))}, both round-to-nearest-even"""
+    def bf16_rne(v):
+        u = v.view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+        return r
+    v = np.ascontiguousarray(x.numpy(), dtype=np.float32)
+    hi = bf16_rne(v)
+    lo = bf16_rne(v - (hi << 16).view(np.float32))
+    return torch.from_numpy(((hi << 16) | lo).view(np.float32).copy())
+
+
+@pytest.mark.gpu
+def test_split_word_interchange_is_bit_identical(ops):
+    """The split {hi | lo} word form of activations / gradients between the bf16x3 kernels (include/nq_hip.h NQ_EPI_X_SPLIT /
+    NQ_EPI_Y_SPLIT, round 4): a consumer fed split words computes the SAME bits as when it splits the floats itself, and a
+    producer asked for split words writes exactly the split of what it writes otherwise.  Shapes: the tiled kernels of dec4 /
+    dec5 of both 3M models at reduced resolution (64-, 80-, 48- and 32-channel tiles), a ragged image, the head data gradient."""
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randn(3, 70, generator=g) * torch.tensor([1e-3, 1.0, 300.0]).view(3, 1)
+    assert torch.equal(ops.split_words(x0.to(DEV)).cpu().view(torch.int32), _split_words_host(x0).view(torch.int32))
+    for B, cin, H, W, cout, k, r in [(2, 44, 128, 128, 148, 5, 2), (2, 53, 128, 128, 176, 5, 2), (2, 24, 128, 128, 96, 3, 2), (1, 36, 80, 160, 384, 3, 4),
+                                     (2, 148, 128, 256, 44, 5, 2), (2, 96, 128, 256, 24, 3, 2), (2, 44, 75, 150, 148, 5, 2)]:
+        x = torch.randn(B, cin, H, W, generator=g).to(DEV)
+        w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(DEV)
+        b = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+        io = ops.conv3_split_io(B, cin, H, W, cout, k)
+        assert io == (ops.EPI_X_SPLIT | ops.EPI_Y_SPLIT), (cin, cout, io)
+        wt3 = ops.weight_layout3(w)
+        xs = ops.split_words(x)
+        if cout % (r * r) == 0 and W % 2 == 0:
+            y, z = ops.conv3_forward_raw(x, wt3, b, cout, k, ops.EPI_PS_GELU, r)
+            y1, z1 = ops.conv3_forward_raw(xs, wt3, b, cout, k, ops.EPI_PS_GELU, r, fmt=ops.EPI_X_SPLIT)
+            assert torch.equal(y, y1) and torch.equal(z, z1)
+            y2, z2 = ops.conv3_forward_raw(xs, wt3, b, cout, k, ops.EPI_PS_GELU, r, fmt=ops.EPI_X_SPLIT | ops.EPI_Y_SPLIT)
+            assert torch.equal(z, z2) and torch.equal(ops.split_words(y).view(torch.int32), y2.view(torch.int32))
+        if H % 2 == 0 and W % 2 == 0:   # data-gradient epilogue (wide and narrow variants), un-shuffle 2
+            zp = torch.rand(B, cout, H, W, generator=g).to(DEV)
+            d, _ = ops.conv3_forward_raw(x, wt3, None, cout, k, ops.EPI_DGRAD_GELU, 2, zprev=zp)
+            d2, _ = ops.conv3_forward_raw(xs, wt3, None, cout, k, ops.EPI_DGRAD_GELU, 2, zprev=zp, fmt=ops.EPI_X_SPLIT | ops.EPI_Y_SPLIT)
+            assert torch.equal(ops.split_words(d).view(torch.int32), d2.view(torch.int32))
+        p, _ = ops.conv3_forward_raw(x, wt3, b, cout, k, ops.EPI_PLAIN, 1)
+        p2, _ = ops.conv3_forward_raw(xs, wt3, b, cout, k, ops.EPI_PLAIN, 1, fmt=ops.EPI_X_SPLIT | ops.EPI_Y_SPLIT)
+        assert torch.equal(ops.split_words(p).view(torch.int32), p2.view(torch.int32))
+    # weight gradient (row-segment producer/consumer kernel): dw bit-identical for split x, split dy, both; db = sum of hi + lo
+    for B, cin, H, W, cout, k in [(2, 44, 64, 128, 148, 5), (2, 24, 128, 256, 96, 3), (2, 53, 32, 128, 176, 5)]:
+        assert ops.conv_wgrad3_split_io(B, cin, H, W, cout, k) == 3, (cin, cout)
+        x = torch.randn(B, cin, H, W, generator=g).to(DEV)
+        dy = torch.randn(B, cout, H, W, generator=g).to(DEV)
+        dw, db = ops.conv_wgrad3_raw(x, dy, cout, k, True)
+        xs, ds = ops.split_words(x), ops.split_words(dy)
+        for fmt, xa, da in ((1, xs, dy), (2, x, ds), (3, xs, ds)):
+            dw1, db1 = ops.conv_wgrad3_raw(xa, da, cout, k, True, fmt=fmt)
+            assert torch.equal(dw, dw1), fmt
+            if fmt & 2:
+                w_ = ds.view(torch.int32)
+                val = ((w_ & -65536).view(torch.float32).double() + (w_ << 16).view(torch.float32).double()).sum((0, 2, 3))
+                close(db1, val, rtol=1e-5, atol=1e-4)
+            else:
+                assert torch.equal(db, db1)
+    # formats a kernel does not offer are refused, not ignored
+    with pytest.raises(Exception):
+        ops.conv3_forward_raw(torch.zeros(2, 77, 10, 20, device=DEV), ops.weight_layout3(torch.zeros(1024, 77, 3, 3, device=DEV)), None, 1024, 3,
+                              ops.EPI_PLAIN, 1, fmt=ops.EPI_X_SPLIT)
+    # the head's streaming data gradient writes split words on request
+    hdy = torch.randn(2, 3, 64, 256, generator=g).to(DEV)
+    hw = (torch.randn(3, 37, 3, 3, generator=g) / (37 * 9) ** 0.5).to(DEV)
+    hz = torch.rand(2, 37, 64, 256, generator=g).to(DEV)
+    _, _, hwb, hdims_b = ops.weight_layouts(hw, True)
+    assert ops.conv_split_out(2, 3, 64, 256, 37, 3, 2, ops.EPI_DGRAD_GELU)
+    hd, _ = ops.conv_forward_raw(hdy, hwb, hdims_b, None, 37, 3, ops.EPI_DGRAD_GELU, 2, zprev=hz)
+    hd2, _ = ops.conv_forward_raw(hdy, hwb, hdims_b, None, 37, 3, ops.EPI_DGRAD_GELU, 2, zprev=hz, fmt=ops.EPI_Y_SPLIT)
+    assert torch.equal(ops.split_words(hd).view(torch.int32), hd2.view(torch.int32))
+
+
 def test_few_pixel_layers_take_the_flat_kernel():
     """The plan of conv_flat3.hip (pure host function behind nq_conv3_supported / nq_conv_forward3_ws_floats): the deep layers of
     both 3M models are offered to it, the big ones are not, and only long K loops on small grids leave slabs."""
