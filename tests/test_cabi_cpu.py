@@ -92,6 +92,32 @@ def test_few_pixel_layers_are_routed_to_the_flat_kernels():
     assert lib.nq_head_forward_loss_ws_floats(2, 640, 1280) == 2 * 5 * 160 * 4       # 4 floats per (frame, 256-column strip, 4-row block)
 
 
+def test_split_word_interchange_plan():
+    """ABI v5, host-only: which side of which launch offers the split {hi | lo} word form (include/nq_hip.h NQ_EPI_X_SPLIT /
+    NQ_EPI_Y_SPLIT).  The tiled bf16x3 kernels of the big layers take and write it, the row-segment weight gradient takes both
+    operands, the streaming head data gradient writes it; split-K launches do not write it, the few-pixel kernels, the 4-wave
+    weight gradient and everything that is not bf16x3 know nothing of it."""
+    from neuroquant_amd import _lib
+    lib = _lib.lib()
+    X, Y = 0x100, 0x200
+    for shape in [(2, 44, 320, 640, 148, 5), (2, 148, 320, 640, 44, 5), (2, 53, 160, 320, 176, 5), (2, 176, 160, 320, 53, 5), (2, 64, 40, 80, 848, 5),
+                  (2, 24, 320, 640, 96, 3), (2, 96, 320, 640, 24, 3), (2, 24, 160, 320, 96, 3), (2, 89, 480, 960, 296, 5)]:
+        assert lib.nq_conv3_split_io(*shape) == X | Y, shape
+    assert lib.nq_conv3_split_io(2, 848, 40, 80, 64, 5) == X            # HNeRV dec3 data gradient: split-K, the finish kernel writes floats
+    for shape in [(2, 77, 10, 20, 1024, 3), (2, 145, 2, 4, 1800, 3), (2, 5, 6, 7, 8, 3), (2, 44, 320, 640, 148, 7)]:
+        assert lib.nq_conv3_split_io(*shape) == 0, shape                 # few-pixel kernels, toy layer, unsupported k
+    for shape in [(2, 44, 320, 640, 148, 5), (2, 53, 160, 320, 176, 5), (2, 64, 40, 80, 848, 5), (2, 24, 320, 640, 96, 3), (2, 24, 160, 320, 96, 3)]:
+        assert lib.nq_conv_wgrad3_split_io(*shape) == 3, shape
+    for shape in [(2, 77, 10, 20, 1024, 3), (2, 36, 40, 80, 384, 3), (2, 3, 640, 1280, 37, 3)]:
+        assert lib.nq_conv_wgrad3_split_io(*shape) == 0, shape           # few-pixel, 4-wave and the role-swapped head kernels
+    # nq_conv_split_out(B, Cin, H, W, Cout, k, r, epilogue, in_gelu, has_bias): the head's data gradient 3 -> 37 / 3 -> 24, un-shuffle 2
+    assert lib.nq_conv_split_out(2, 3, 640, 1280, 37, 3, 2, 4, 0, 0) == 1
+    assert lib.nq_conv_split_out(2, 3, 640, 1280, 24, 3, 2, 4, 0, 0) == 1
+    assert lib.nq_conv_split_out(2, 3, 640, 1280, 37, 3, 2, 4, 0, 1) == 0   # (a bias: not the data gradient)
+    assert lib.nq_conv_split_out(2, 37, 640, 1280, 3, 3, 1, 2, 0, 1) == 0   # the head forward
+    assert lib.nq_conv_split_out(2, 44, 320, 640, 148, 5, 2, 1, 0, 1) == 0  # an fp32 matrix-pipe layer
+
+
 def test_ops_refuse_cpu_tensors():
     from neuroquant_amd import ops
     with pytest.raises(RuntimeError):
