@@ -557,10 +557,13 @@ int nq_weight_layouts_all(const nq_wl3_seg* segs3, int n3, const nq_wl_seg* segs
 
 // Which sides of nq_conv_forward3 may travel as split {hi | lo} words for this shape: bit NQ_EPI_X_SPLIT -- the input (the tiled
 // kernel with >= 32-channel tiles stages it), bit NQ_EPI_Y_SPLIT -- the output y (the tiled kernel's own epilogue writes it: no
-// split-K).  0 for the few-pixel kernels and for shapes this path does not serve.
+// split-K; the few-pixel kernel when it leaves no slabs).  0 for shapes this path does not serve.
 int nq_conv3_split_io(int B, int Cin, int H, int W, int Cout, int k) {
   if (!nq_conv3_supported(B, Cin, H, W, Cout, k)) return 0;
-  if (use_flat3(B, Cin, H, W, Cout, k, nullptr)) return 0;
+  {   // few-pixel kernel: reads floats only; writes the words when it needs no slabs (its own epilogue runs)
+    int fns = 1;
+    if (use_flat3(B, Cin, H, W, Cout, k, &fns)) return fns == 1 ? NQ_EPI_Y_SPLIT : 0;
+  }
   const Fwd3Plan p = plan_fwd3(B, Cin, H, W, Cout);
   return (p.mi >= 2 ? NQ_EPI_X_SPLIT : 0) | (p.nsplit == 1 ? NQ_EPI_Y_SPLIT : 0);
 }
@@ -583,7 +586,7 @@ int nq_conv_forward3(const float* x, const void* wt3, const float* bias, float* 
     if (use_flat3(B, Cin, H, W, Cout, k, &fns)) {
       if (fns > 1 && !ws) return NQ_ERR_INVALID;
       const int mi = pick_mi3(Cout), kind = tail_kind_of(Cin, mi);
-      int rc = nq_conv_flat3(x, wt3, bias, y, z, zprev, ws, B, Cin, H, W, Cout, k, r, epilogue, 16 * mi, kind, nst_of(k),
+      int rc = nq_conv_flat3(x, wt3, bias, y, z, zprev, ws, B, Cin, H, W, Cout, k, r, epilogue | fmt, 16 * mi, kind, nst_of(k),
                              nstk_of(k, kind), st);
       if (rc != NQ_OK || fns == 1) return rc;
       return nq_conv_splitk_finish(ws, bias, y, z, zprev, B, H, W, Cout, r, epilogue, fns, st);

@@ -53,6 +53,7 @@ struct FlatArgs {
   int nchunk, tail, NST, NSTT;
   int ngroups, cgroups;    // pixel groups (16*NB pixels) and channel groups (16*MI channels) of the grid
   int nsplit, per_split;   // workgroup-level split over chunks
+  int y_split;             // y as split {hi | lo} words (only with nsplit == 1)
   int ppix;                // 16-byte units per (plane, octet) of a wave's patch
   unsigned x_bytes;
   FDiv dHW, dW, dVH, dNQ, dR, dRR, dNG, dCG;
@@ -293,13 +294,14 @@ __global__ __launch_bounds__(NW * 64) void conv_flat3_kernel(FlatArgs a) {
         if (epi == NQ_EPI_PS_GELU) {
           float gv, dv;
           nq_gelu_pair(val, gv, dv);
-          a.y[o] = gv;
+          a.y[o] = a.y_split ? nq_split_word_f(gv) : gv;
           a.z[o] = dv;
         } else {
           a.z[o] = val;
         }
       } else if (epi == NQ_EPI_DGRAD_GELU) {
         val *= a.zprev[i];
+        if (a.y_split) val = nq_split_word_f(val);
         if (r == 1) {
           a.y[i] = val;
         } else {
@@ -308,7 +310,8 @@ __global__ __launch_bounds__(NW * 64) void conv_flat3_kernel(FlatArgs a) {
           a.y[(((int64_t)b * Cout * rr + ch) * (H / r) + yq) * (int64_t)(W / r) + xq] = val;
         }
       } else {
-        a.y[i] = (epi == NQ_EPI_TANH) ? tanhf(val) * 0.5f + 0.5f : val;
+        const float ov = (epi == NQ_EPI_TANH) ? tanhf(val) * 0.5f + 0.5f : val;
+        a.y[i] = a.y_split ? nq_split_word_f(ov) : ov;
       }
     }
   }
@@ -369,6 +372,10 @@ extern "C" int nq_conv_flat3(const float* x, const void* wt3, const float* bias,
   if (!nq_conv_flat3_plan(B, Cin, H, W, Cout, k, &NWv, &NBv, &ns, &per)) return NQ_ERR_UNSUPPORTED;
   FlatArgs a{};
   a.x = x; a.wt3 = reinterpret_cast<const u32x4*>(wt3); a.bias = bias; a.y = y; a.z = z; a.zprev = zprev; a.slab = slab;
+  // bit 9 of `epi` (NQ_EPI_Y_SPLIT): y is written as split {hi | lo} words (nq_common.h) -- only without split-K
+  a.y_split = (epi & 0x200) ? 1 : 0;
+  epi &= 0xFF;
+  if (a.y_split && ns > 1) return NQ_ERR_UNSUPPORTED;
   a.B = B; a.Cin = Cin; a.H = H; a.W = W; a.Cout = Cout; a.KS = k; a.r = r; a.epi = epi;
   a.P = B * H * W;
   a.MT = MT; a.co_tiles = (Cout + MT - 1) / MT;

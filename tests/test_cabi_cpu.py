@@ -104,8 +104,11 @@ def test_split_word_interchange_plan():
                   (2, 24, 320, 640, 96, 3), (2, 96, 320, 640, 24, 3), (2, 24, 160, 320, 96, 3), (2, 89, 480, 960, 296, 5)]:
         assert lib.nq_conv3_split_io(*shape) == X | Y, shape
     assert lib.nq_conv3_split_io(2, 848, 40, 80, 64, 5) == X            # HNeRV dec3 data gradient: split-K, the finish kernel writes floats
-    for shape in [(2, 77, 10, 20, 1024, 3), (2, 145, 2, 4, 1800, 3), (2, 5, 6, 7, 8, 3), (2, 44, 320, 640, 148, 7)]:
-        assert lib.nq_conv3_split_io(*shape) == 0, shape                 # few-pixel kernels, toy layer, unsupported k
+    for shape in [(2, 77, 10, 20, 1024, 3), (2, 145, 2, 4, 1800, 3)]:
+        assert lib.nq_conv3_split_io(*shape) == Y, shape                 # few-pixel forward without slabs: writes, never reads
+    assert lib.nq_conv3_split_io(2, 1024, 10, 20, 77, 3) == X           # HNeRV dec2 data gradient: tiled, split-K
+    for shape in [(2, 5, 6, 7, 8, 3), (2, 44, 320, 640, 148, 7)]:
+        assert lib.nq_conv3_split_io(*shape) == 0, shape                 # toy layer, unsupported k
     for shape in [(2, 44, 320, 640, 148, 5), (2, 53, 160, 320, 176, 5), (2, 64, 40, 80, 848, 5), (2, 24, 320, 640, 96, 3), (2, 24, 160, 320, 96, 3)]:
         assert lib.nq_conv_wgrad3_split_io(*shape) == 3, shape
     for shape in [(2, 77, 10, 20, 1024, 3), (2, 36, 40, 80, 384, 3), (2, 3, 640, 1280, 37, 3)]:

@@ -390,6 +390,14 @@ def test_split_word_interchange_is_bit_identical(ops):
                 close(db1, val, rtol=1e-5, atol=1e-4)
             else:
                 assert torch.equal(db, db1)
+    # the few-pixel forward kernel writes the words too (HNeRV dec2 -> the input of dec3), and refuses to read them
+    fx = torch.randn(2, 77, 10, 20, generator=g).to(DEV)
+    fw = (torch.randn(1024, 77, 3, 3, generator=g) / (77 * 9) ** 0.5).to(DEV)
+    fb = (torch.randn(1024, generator=g) * 0.1).to(DEV)
+    assert ops.conv3_split_io(2, 77, 10, 20, 1024, 3) == ops.EPI_Y_SPLIT
+    fy, fz = ops.conv3_forward_raw(fx, ops.weight_layout3(fw), fb, 1024, 3, ops.EPI_PS_GELU, 4)
+    fy2, fz2 = ops.conv3_forward_raw(fx, ops.weight_layout3(fw), fb, 1024, 3, ops.EPI_PS_GELU, 4, fmt=ops.EPI_Y_SPLIT)
+    assert torch.equal(fz, fz2) and torch.equal(ops.split_words(fy).view(torch.int32), fy2.view(torch.int32))
     # formats a kernel does not offer are refused, not ignored
     with pytest.raises(Exception):
         ops.conv3_forward_raw(torch.zeros(2, 77, 10, 20, device=DEV), ops.weight_layout3(torch.zeros(1024, 77, 3, 3, device=DEV)), None, 1024, 3,
