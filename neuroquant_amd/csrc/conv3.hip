@@ -313,13 +313,13 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
   // narrow problems streaming a big tensor (the role-swapped head gradient: 3 x 9 n-values, K = all pixels): the 4-wave
   // kernel runs 18 MFMAs per barrier with one 6 KB segment in flight per workgroup (latency-bound, 2.1 TB/s); the
   // producer/consumer kernel with 128-pixel segments keeps 2 x 24 KB in flight per CU
-  if (pc_ok && p.ni == 1 && (p.mi == 2 || p.mi == 3) && tiles == 1 && W % 128 == 0) {
+  if (pc_ok && p.ni == 1 && p.mi >= 2 && p.mi <= 5 && tiles == 1 && W % 128 == 0) {
     const int nseg_pc = (W / 128) * H * B;
     if (nseg_pc / 256 >= 8) {
       p.pc = 4;
       // NQ_WGRAD3_HEAD_SPLITS (timing runs): 256 = one 8-wave workgroup per CU (round 2), 512 = two
       static const int hs = [] { const char* e = std::getenv("NQ_WGRAD3_HEAD_SPLITS"); return e ? atoi(e) : 512; }();
-      p.nsplit = (nseg_pc / hs >= 8) ? hs : 256;
+      p.nsplit = (p.mi <= 3 && nseg_pc / hs >= 8) ? hs : 256;   // (64- / 80-channel tiles: one workgroup per CU)
     }
   }
   return p;

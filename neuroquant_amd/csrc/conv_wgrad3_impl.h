@@ -379,7 +379,8 @@ constexpr int ni3_for(int mi) { return mi <= 3 ? 6 : (mi <= 4 ? 6 : 6); }
 // are bit-identical for an equal split plan.  One barrier per segment, executed by all eight waves.
 template <int MI, int NI, int SS, int SY>
 // (the narrow streaming variant, NI == 1: few registers, latency-bound -> up to two workgroups per CU, conv3.hip plan_wgrad3)
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(NI == 1 ? 4 : 2, NI == 1 ? 4 : 2))) void conv_wgrad3p_kernel(Wgrad3Args a) {
+// (tiles of more than 48 channels hold too many registers for that: one workgroup per CU)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu((NI == 1 && MI <= 3) ? 4 : 2, (NI == 1 && MI <= 3) ? 4 : 2))) void conv_wgrad3p_kernel(Wgrad3Args a) {
   // A staged segment = SY image rows x 32*SS pixels = SS*SY MFMA k-steps of 32 pixels, one barrier each.
   //   SY > 1 (rows): the KS-row x halo is shared -- KS+SY-1 rows are staged for SY row-steps instead of KS per step
   //   (SY = 4: 2 rows per step instead of 5, the producers' x work and the x traffic drop by 60 %);
@@ -820,6 +821,8 @@ extern "C" int NQ_CAT(nq_conv_wgrad3_k, NQ_KS)(const float* x, const float* dy, 
       switch (mi_sel) {
         case 2: return launch_wgrad3p<2, 1, 4, 1>(a, st);
         case 3: return launch_wgrad3p<3, 1, 4, 1>(a, st);
+        case 4: return launch_wgrad3p<4, 1, 4, 1>(a, st);   // (heads with 49 .. 80 input channels: the UVG-12M shape has 74)
+        case 5: return launch_wgrad3p<5, 1, 4, 1>(a, st);
         default: return NQ_ERR_UNSUPPORTED;
       }
     }

@@ -434,10 +434,20 @@ def test_few_pixel_layers_take_the_flat_kernel():
     assert lib.nq_conv_wgrad3_ws_floats(2, 44, 320, 640, 148, 5) > 1 << 20
 
 
-def test_wgrad_swapped_roles_small_cout(ops):
-    """head-layer weight gradient through the role-swapped bf16x3 kernel == direct fp32 kernel == float64."""
+@pytest.mark.parametrize("shape", ((2, 37, 48, 96), (2, 37, 80, 1920), (2, 74, 80, 1920), (1, 60, 160, 1920)))
+def test_wgrad_swapped_roles_small_cout(ops, shape):
+    """head-layer weight gradient through the role-swapped bf16x3 kernel == direct fp32 kernel == float64.  The wide shapes take
+    the streaming producer/consumer variant (128-pixel segments): 48-channel tile as in the 3M models, and the 64- / 80-channel
+    tiles (one workgroup per CU) that heads with 49 .. 80 input channels use (the UVG-12M shape has 74)."""
     g = torch.Generator().manual_seed(11)
-    B, Cin, H, W, Cout, k = 2, 37, 48, 96, 3, 3
+    B, Cin, H, W = shape
+    Cout, k = 3, 3
+    if W % 128 == 0:
+        from neuroquant_amd import _lib
+        import ctypes
+        mi, ni, ns, pc = (ctypes.c_int() for _ in range(4))
+        assert _lib.lib().nq_conv_wgrad3_plan(B, Cout, H, W, Cin, k, ctypes.byref(mi), ctypes.byref(ni), ctypes.byref(ns), ctypes.byref(pc)) == 0
+        assert pc.value == 4 and ni.value == 1 and mi.value == (Cin + 15) // 16, (mi.value, ni.value, ns.value, pc.value)
     x, dy = torch.randn(B, Cin, H, W, generator=g), torch.randn(B, Cout, H, W, generator=g)
     ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, k, k), dy.double(), padding=1)
     dw, db = ops.conv_wgrad_swapped3(x.to(DEV), dy.to(DEV), Cout, k, True)
