@@ -278,10 +278,21 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
     }
     p.ni = best;
   }
-  const int mt = 16 * p.mi, nt = 64 * p.ni;
+  int mt = 16 * p.mi, nt = 64 * p.ni;
   p.co_pad = (Cout + mt - 1) / mt * mt;
   p.n_pad = (N + nt - 1) / nt * nt;
-  const int tiles = (p.co_pad / mt) * (p.n_pad / nt);
+  int tiles = (p.co_pad / mt) * (p.n_pad / nt);
+  // Very wide layers (more than 256 output tiles: the UVG-12M shape's 128 -> 1712) fell off the producer/consumer kernel, which
+  // wants one workgroup per CU in ONE round: the 80-channel tile gets them back under 256 when its extra padding is small
+  if (tiles > 256 && p.mi < 5 && p.ni >= 5) {
+    const int co5 = (Cout + 79) / 80 * 80, tiles5 = (co5 / 80) * (p.n_pad / nt);
+    if (tiles5 <= 256 && co5 * 100 <= p.co_pad * 105) {
+      p.mi = 5;
+      mt = 80;
+      p.co_pad = co5;
+      tiles = tiles5;
+    }
+  }
   const int nseg = ((W + 31) / 32) * H * B;
   int ns = 512 / tiles;  // one full wave of workgroups (2 resident per CU)
   if (ns > nseg) ns = nseg;

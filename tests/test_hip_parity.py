@@ -311,6 +311,8 @@ def test_conv_bf16x3(ops, case):
                                   # enough 32-pixel segments per workgroup for the producer/consumer kernel (8 waves, one
                                   # workgroup per CU): dec5 / dec4 channel geometry, ragged last segment in the second
                                   (2, 44, 48, 224, 148, 5), (1, 53, 66, 216, 176, 5), (2, 36, 128, 256, 96, 3),
+                                  # a very wide layer (UVG-12M's 128 -> 1712): 80-channel tiles keep it on that kernel, one split
+                                  (1, 128, 24, 96, 1712, 5),
                                   # few-pixel layers (conv_wgrad_flat3.hip: all pixels of all frames = the K dimension, no split-K, no
                                   # slabs): HNeRV dec2, NeRV dec1 / dec2, k = 5, a ragged last k-step (72 pixels), ragged tiles
                                   (2, 77, 10, 20, 1024, 3), (2, 145, 2, 4, 1800, 3), (2, 72, 10, 20, 576, 3), (1, 30, 8, 8, 100, 5),
