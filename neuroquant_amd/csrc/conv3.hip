@@ -316,7 +316,12 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
       else if (H % 2 == 0 && segs_x * (H / 2) * B / ns_pc >= minseg) sy = 2;
     }
     const int nseg_pc = segs_x * (H / sy) * B;
-    if (ns_pc >= 1 && nseg_pc / ns_pc >= (minseg < 16 ? minseg : 16)) {
+    const int need = minseg < 16 ? minseg : 16;
+    // a little short of segments for one workgroup per CU (NeRV-3M's 36 -> 384 at 40 x 80: 240 one-row segments for 42 splits):
+    // fewer splits, as long as three quarters of the CUs still get a workgroup (NQ_WGRAD3_SHRINK=0: the 4-wave kernel as before)
+    static const int shrink = [] { const char* e = std::getenv("NQ_WGRAD3_SHRINK"); return e ? atoi(e) : 1; }();
+    if (shrink && ns_pc >= 1 && nseg_pc / ns_pc < need && (nseg_pc / need) * tiles >= 192) ns_pc = nseg_pc / need;
+    if (ns_pc >= 1 && nseg_pc / ns_pc >= need) {
       p.pc = sy == 1 ? 1 : 10 + sy;
       p.nsplit = ns_pc;
     }
