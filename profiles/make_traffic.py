@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """profiles/hbm_traffic.json (what bench.py reports as roofline.traffic) from a PMC summary made by summarize.py.
 
-    python3 profiles/make_traffic.py profiles/r04_e_pmc_conv_kernels.json profiles/r04_e_nerv_pmc_conv_kernels.json \
-        profiles/r04_fp32_pmc_conv_kernels.json profiles/r04_e_uvg_pmc_conv_kernels.json
+    python3 profiles/make_traffic.py profiles/r04_f_pmc_conv_kernels.json profiles/r04_f_nerv_pmc_conv_kernels.json \
+        profiles/r04_fp32_pmc_conv_kernels.json profiles/r04_f_uvg_pmc_conv_kernels.json
 
 bytes = read + write per launch at per-GPU batch 2: FETCH_SIZE x 2 (gfx950 reports half the bytes of 16-byte-per-lane
 streaming reads, MI355X_MICROARCH.md §HBM; separate --pmc pass) + WRITE_SIZE (its own pass).  FETCH_SIZE counts the L2's
@@ -16,23 +16,23 @@ import sys
 # bench key -> (kernel name in the PMC summary, grid size, tag of the summary file it must come from)
 # (conv_igemm3_kernel<MI, WPE, XS>: channel blocks per tile, waves per SIMD the build aims at, input as split {hi | lo} words)
 MAP = {
-    # HNeRV Bunny_1280x640_3M, B = 2, bf16x3 (r04_e)
-    "conv_wgrad3_k5_44_148": ("conv_wgrad3p_kernel<5, 6, 1, 4>", 129024, "r04_e_pmc"),
-    "conv_igemm3_k5_44_148": ("conv_igemm3_kernel<5, 2, true>", 819200, "r04_e_pmc"),
-    "conv_igemm3_k5_148_44": ("conv_igemm3_kernel<3, 2, true>", 409600, "r04_e_pmc"),
-    "conv_wgrad3_k5_53_176": ("conv_wgrad3p_kernel<4, 7, 1, 4>", 129024, "r04_e_pmc"),
-    "conv_igemm3_k5_53_176": ("conv_igemm3_kernel<4, 2, true>", 307200, "r04_e_pmc"),
-    "conv_igemm3_k5_176_53": ("conv_igemm3_kernel<4, 2, true>", 102400, "r04_e_pmc"),
-    # NeRV Bunny_1280x640_3M + Hadamard (r04_e_nerv): the `nerv` object's dominant kernel
-    "conv_igemm3_k3_24_96": ("conv_igemm3_kernel<3, 3, true>", 819200, "r04_e_nerv_pmc"),
+    # HNeRV Bunny_1280x640_3M, B = 2, bf16x3 (r04_f)
+    "conv_wgrad3_k5_44_148": ("conv_wgrad3p_kernel<5, 6, 1, 4>", 129024, "r04_f_pmc"),
+    "conv_igemm3_k5_44_148": ("conv_igemm3_kernel<5, 2, true>", 819200, "r04_f_pmc"),
+    "conv_igemm3_k5_148_44": ("conv_igemm3_kernel<3, 2, true>", 409600, "r04_f_pmc"),
+    "conv_wgrad3_k5_53_176": ("conv_wgrad3p_kernel<4, 7, 1, 4>", 129024, "r04_f_pmc"),
+    "conv_igemm3_k5_53_176": ("conv_igemm3_kernel<4, 2, true>", 307200, "r04_f_pmc"),
+    "conv_igemm3_k5_176_53": ("conv_igemm3_kernel<4, 2, true>", 102400, "r04_f_pmc"),
+    # NeRV Bunny_1280x640_3M + Hadamard (r04_f_nerv): the `nerv` object's dominant kernel
+    "conv_igemm3_k3_24_96": ("conv_igemm3_kernel<3, 3, true>", 819200, "r04_f_nerv_pmc"),
     # the same HNeRV workload with exact-fp32 convolutions (r04_fp32): the `fp32` object
     "conv_igemm_k5_44_148": ("conv_igemm_kernel<10>", 819200, "r04_fp32_pmc"),
     "conv_igemm_k5_148_44": ("conv_igemm_kernel<3>", 819200, "r04_fp32_pmc"),
     "conv_wgrad_k5_44_148": ("conv_wgrad_kernel<10, 3>", 130560, "r04_fp32_pmc"),
-    # HNeRV UVG 960x1920 ~12M (r04_e_uvg): the `uvg` object
-    "conv_wgrad3_k5_89_296": ("conv_wgrad3p_kernel<4, 7, 1, 4>", 128000, "r04_e_uvg_pmc"),
-    "conv_igemm3_k5_89_296": ("conv_igemm3_kernel<4, 2, true>", 4608000, "r04_e_uvg_pmc"),
-    "conv_igemm3_k5_296_89": ("conv_igemm3_kernel<3, 2, true>", 1843200, "r04_e_uvg_pmc"),
+    # HNeRV UVG 960x1920 ~12M (r04_f_uvg): the `uvg` object
+    "conv_wgrad3_k5_89_296": ("conv_wgrad3p_kernel<4, 7, 1, 4>", 128000, "r04_f_uvg_pmc"),
+    "conv_igemm3_k5_89_296": ("conv_igemm3_kernel<4, 2, true>", 4608000, "r04_f_uvg_pmc"),
+    "conv_igemm3_k5_296_89": ("conv_igemm3_kernel<3, 2, true>", 1843200, "r04_f_uvg_pmc"),
 }
 
 
