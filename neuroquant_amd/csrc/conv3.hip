@@ -284,7 +284,9 @@ inline Wg3Plan plan_wgrad3(int B, int Cin, int H, int W, int Cout, int k) {
   int tiles = (p.co_pad / mt) * (p.n_pad / nt);
   // Very wide layers (more than 256 output tiles: the UVG-12M shape's 128 -> 1712) fell off the producer/consumer kernel, which
   // wants one workgroup per CU in ONE round: the 80-channel tile gets them back under 256 when its extra padding is small
-  if (tiles > 256 && p.mi < 5 && p.ni >= 5) {
+  // (preferring them wherever they pad no more -- HNeRV-3M's 64 -> 848: 880 instead of 896 rows -- measured 66-68 -> 65 us with one
+  // more slab to reduce: not kept)
+  if (tiles > 256 && p.mi < 5 && p.ni >= 5 && p.ni <= 6 /* (no 80 x 448 tile) */) {
     const int co5 = (Cout + 79) / 80 * 80, tiles5 = (co5 / 80) * (p.n_pad / nt);
     if (tiles5 <= 256 && co5 * 100 <= p.co_pad * 105) {
       p.mi = 5;
